@@ -1,0 +1,226 @@
+/*
+ * rthip.h — C ABI of the MI355X (gfx950) render path for rustracer's raytracer_core.
+ *
+ * This is the drop-in boundary: the entry points are what a
+ * `raytracer_hip` Rust crate binds with `extern "C"` (see INTEGRATION.md and
+ * raytracer_hip/src/ffi.rs) to replace the per-pixel render loop
+ *     raytracer_core/src/lib.rs:269-316   Raytracer::generate_pixel
+ *     raytracer_core/src/camera.rs:43-50  Camera::emit_ray_at
+ *     raytracer_core/src/shapes/ray.rs:42-93  project_ray / find_collision / background_color
+ *     raytracer_core/src/shapes/sphere.rs:29-73, materials/{...}.rs  collide / scatter / bounce
+ * All file:line citations are relative to /root/reference.
+ *
+ * Conventions
+ *  - Every struct is POD with fixed-width members and explicit padding; no bool.
+ *  - Host pointers inside a struct are BORROWED for the duration of the call and copied.
+ *  - Return value: 0 = OK, negative = rthip_status. The message of the last failure on a
+ *    context is available from rthip_last_error(). No C++ exception crosses the boundary.
+ *  - A context is bound to ONE device and is NOT thread-safe (the reference has a single
+ *    render thread, standalone/src/main.rs:65). Multi-GPU = one context per device/process;
+ *    the row-band parameters of rthip_render_params select the rows a device owns.
+ *  - Image rows are y-up as in the reference: row 0 of every output buffer is pos.y = 0,
+ *    the BOTTOM row of the picture (raytracer_core/src/lib.rs:282-285; the display flips
+ *    it in standalone/src/renderers/pixels.rs:243).
+ *  - Scene geometry is given in double (the reference is f64 throughout); the device
+ *    computes in FP32.
+ */
+#ifndef RTHIP_H
+#define RTHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTHIP_ABI_VERSION 1
+
+typedef enum rthip_status {
+    RTHIP_OK = 0,
+    RTHIP_E_BADARG = -1,
+    RTHIP_E_HIP = -2,
+    RTHIP_E_OOM = -3,
+    RTHIP_E_NODEVICE = -4,
+    RTHIP_E_STATE = -5, /* call order: render before scene/camera upload */
+    RTHIP_E_INTERNAL = -6
+} rthip_status;
+
+/* ---- materials: raytracer_core/src/materials/{lambertian_diffuse,metal,dielectric,texture}.rs ---- */
+enum {
+    RTHIP_MAT_LAMBERTIAN = 0, /* Lambertian::new(albedo)            lambertian_diffuse.rs:19 */
+    RTHIP_MAT_METAL = 1,      /* Metal::new(albedo, fuzziness)      metal.rs:19              */
+    RTHIP_MAT_DIELECTRIC = 2, /* Dielectric::new(albedo, ior)       dielectric.rs:20         */
+    RTHIP_MAT_TEXTURE = 3     /* Texture::load_from_file(path,scale) texture.rs:21           */
+};
+
+typedef struct rthip_material {
+    uint32_t kind;    /* RTHIP_MAT_* */
+    uint32_t texture; /* TEXTURE: index into rthip_scene_desc.textures */
+    double albedo[3]; /* the albedo AS PASSED to ::new (the constructors divide by PI themselves) */
+    double param;     /* METAL: fuzziness; DIELECTRIC: refraction_idx; TEXTURE: scale */
+    double shininess; /* extension (point-light mode only): Phong exponent, 0 = no specular lobe */
+} rthip_material;
+
+/* Decoded image of a Texture material (texture.rs:14-30): tightly packed RGB8, row 0 = top. */
+typedef struct rthip_texture {
+    uint32_t width;
+    uint32_t height;
+    const uint8_t *rgb8; /* width*height*3 bytes, borrowed */
+} rthip_texture;
+
+/* Sphere::new(center, radius, material)   raytracer_core/src/shapes/sphere.rs:12-25 */
+typedef struct rthip_sphere {
+    double center[3];
+    double radius;
+    uint32_t material;
+    uint32_t _pad;
+} rthip_sphere;
+
+/* Extension (no reference counterpart; plugs in where `impl Shape` would, shapes/shape.rs:7-15). */
+typedef struct rthip_plane {
+    double point[3];
+    double normal[3]; /* need not be unit; normalised on upload */
+    uint32_t material;
+    uint32_t _pad;
+} rthip_plane;
+
+/* Extension: triangle, counter-clockwise front face; texture UV = barycentric (b1, b2). */
+typedef struct rthip_triangle {
+    double v0[3];
+    double v1[3];
+    double v2[3];
+    uint32_t material;
+    uint32_t _pad;
+} rthip_triangle;
+
+/* Extension: point light for the optional direct-lighting mode (RTHIP_F_POINT_LIGHTS). */
+typedef struct rthip_light {
+    double position[3];
+    double intensity[3];
+} rthip_light;
+
+/*
+ * The scene: what the reference holds as `Scene = Vec<Box<dyn Shape>>` (lib.rs:75).
+ * Shape index (tie-break of find_collision, ray.rs:51-65, and rthip_pick): spheres first in
+ * array order, then planes, then triangles.
+ */
+typedef struct rthip_scene_desc {
+    const rthip_sphere *spheres;
+    uint64_t n_spheres;
+    const rthip_plane *planes;
+    uint64_t n_planes;
+    const rthip_triangle *triangles;
+    uint64_t n_triangles;
+    const rthip_material *materials;
+    uint64_t n_materials;
+    const rthip_texture *textures;
+    uint64_t n_textures;
+    const rthip_light *lights;
+    uint64_t n_lights;
+} rthip_scene_desc;
+
+/* Camera constants as recoverable from the reference's public API:
+ * origin = camera.origin; d00 = emit_ray_at(0,0).direction();
+ * horizontal = emit_ray_at(1,0).direction() - d00; vertical = emit_ray_at(0,1).direction() - d00. */
+typedef struct rthip_camera {
+    double origin[3];
+    double d00[3]; /* lower_left_corner - origin   camera.rs:46 */
+    double horizontal[3];
+    double vertical[3];
+} rthip_camera;
+
+enum {
+    RTHIP_F_ACCUMULATE = 1u << 0,   /* add to the context's running sum (lib.rs:289-294) instead of starting over */
+    RTHIP_F_POINT_LIGHTS = 1u << 1, /* extension: direct light + shadow rays at every scattering hit */
+    RTHIP_F_COUNT_STATS = 1u << 2,  /* run the instrumented kernel and fill rthip_stats counters */
+    RTHIP_F_NO_BVH = 1u << 3        /* force the brute-force linear scan (ray.rs:47-67) even for big scenes */
+};
+
+typedef struct rthip_render_params {
+    uint32_t width;       /* full image width  (u = (x+xi)/(width-1),  lib.rs:282-283) */
+    uint32_t height;      /* full image height (v = (y+xi)/(height-1), lib.rs:284-285) */
+    uint32_t spp;         /* samples per pixel of THIS pass (generate_pixel's `samples`) */
+    uint32_t max_depth;   /* 50 = reference (ray.rs:44) */
+    uint32_t seed;        /* counter-RNG seed (replaces the entropy-seeded SmallRng) */
+    uint32_t flags;       /* RTHIP_F_* */
+    uint32_t band_rows;   /* rows per band R; 0 = the whole image is one band owned by this context */
+    uint32_t band_first;  /* first band owned by this context */
+    uint32_t band_stride; /* this context owns bands band_first + k*band_stride (k = 0,1,...) */
+    uint32_t reserved[7]; /* must be 0 */
+} rthip_render_params;
+
+typedef struct rthip_stats {
+    uint64_t paths;        /* primary paths traced this pass */
+    uint64_t rays;         /* ray segments = find_collision-equivalent queries (primary+bounce+shadow) */
+    uint64_t sphere_tests; /* RTHIP_F_COUNT_STATS only */
+    uint64_t plane_tests;
+    uint64_t tri_tests;
+    uint64_t node_tests;
+    uint64_t rows;         /* rows rendered by this context this pass */
+    uint64_t nb_samples;   /* samples accumulated per pixel so far (PixelCache.nb_samples, lib.rs:72) */
+    double kernel_ms;      /* device time of the render kernel(s), HIP events */
+    double d2h_ms;         /* device->host copy of the outputs (rthip_render only) */
+} rthip_stats;
+
+typedef struct rthip_ctx rthip_ctx;
+
+/* Number of visible HIP devices. */
+int rthip_device_count(int *out_count);
+
+/* Create a context on `device`. Replaces Raytracer::new (lib.rs:250). */
+int rthip_create(int device, rthip_ctx **out_ctx);
+
+/* Flatten the scene to device SoA buffers (and a linear BVH for big scenes).
+ * Replaces the borrowed `&[Box<dyn Shape>]` argument of generate_pixel (lib.rs:272). */
+int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *scene);
+
+/* Replaces the `pub camera: Camera` field (lib.rs:240) read by emit_ray_at (camera.rs:43-50).
+ * Changing the camera invalidates the running sum, like Command::{Move,Rotate} does in
+ * standalone/src/main.rs:103-120. */
+int rthip_set_camera(rthip_ctx *ctx, const rthip_camera *camera);
+
+/* Camera::new_lookat (camera.rs:19-41) evaluated in double on the host. */
+int rthip_camera_lookat(double x, double y, double z, const double lookat[3], rthip_camera *out);
+
+/* Number of rows the context owns for these parameters (output buffers hold rows*width pixels). */
+int rthip_owned_rows(const rthip_render_params *params, uint32_t *out_rows);
+
+/*
+ * Render one pass of `spp` samples for every owned pixel. Replaces the loop
+ *   loop { generate_pixel(gen, scene, spp, renderer); if gen.next().is_none() break }
+ * (wasm/src/lib.rs:112-123). Synchronous; outputs are HOST buffers holding the owned rows in
+ * increasing y, `width` pixels each:
+ *   rgba8_out: owned_rows*width*4 bytes, R,G,B = the u8 of lib.rs:294-299/30-38, A = 255; may be NULL
+ *   accum_out: owned_rows*width*3 floats = the running radiance sum (PixelCache.incremental_raw_light); may be NULL
+ *   stats:     may be NULL
+ */
+int rthip_render(rthip_ctx *ctx, const rthip_render_params *params, uint8_t *rgba8_out, float *accum_out,
+                 rthip_stats *stats);
+
+/*
+ * Same pass, outputs left in DEVICE memory, enqueued on `hip_stream` (a hipStream_t, NULL = the
+ * null stream) without synchronising. d_rgba8 / d_accum are device pointers of the sizes above
+ * (either may be NULL). Used by callers that own device buffers (the multi-GPU gather, benches).
+ * kernel_ms in `stats` is filled only if `stats` is non-NULL, which makes the call synchronous.
+ */
+int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *params, void *d_rgba8, void *d_accum,
+                        void *hip_stream, rthip_stats *stats);
+
+/* Forget the running sum: PixelRenderer::invalidate_pixels / RandomGenerator::invalidate_pixels
+ * (lib.rs:79,120-138). */
+int rthip_reset_accum(rthip_ctx *ctx);
+
+/* Raytracer::get_shape (lib.rs:262-267): un-jittered primary ray through pixel (x, y) of a
+ * width x height image; *out_shape = index of the closest shape, or -1 for a miss. */
+int rthip_pick(rthip_ctx *ctx, uint32_t width, uint32_t height, double x, double y, int64_t *out_shape);
+
+const char *rthip_last_error(const rthip_ctx *ctx);
+const char *rthip_status_string(int status);
+int rthip_abi_version(void);
+
+void rthip_destroy(rthip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTHIP_H */

@@ -1,0 +1,14 @@
+// rt_bvh.h — host-built linear BVH over spheres + triangles (extension: the reference scans
+// linearly, raytracer_core/src/shapes/ray.rs:47-67). Declared here, built in rt_bvh.cpp.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/rthip.h"
+#include "rt_device.h"
+
+// scenes with more bounded primitives than this get a BVH (below it the scalar-load linear scan wins)
+#define RT_BVH_THRESHOLD 64ull
+
+void rt_build_bvh(const rthip_scene_desc *scene, std::vector<DevBvhNode> &nodes, std::vector<uint32_t> &prims);

@@ -1,0 +1,83 @@
+// rt_device.h — device-side data layout of the flattened scene and the kernel parameter block.
+// Shared by rthip_api.cpp (host flattening/upload) and rt_kernels.hip (gfx950 kernels).
+//
+// HBM layout (all arrays 16-byte aligned, read-only during a render):
+//   sph_geom  [n_spheres] float4 {cx, cy, cz, r*r}          -> the closest-hit scan reads ONLY this
+//   sph_shade [n_spheres] float4 {1/r, mat_index(bits), 0, 0} -> read once per hit by the hitting lane
+//   pln_geom  [n_planes]  2 x float4 {nx,ny,nz, n.p0} {mat(bits), 0,0,0} + tangent frame 2 x float4
+//   tri_geom  [n_tris]    3 x float4 {v0, e1, e2} w = mat(bits)/0/0
+//   materials [n_mat]     3 x float4, see DevMaterial
+//   texels    RGBA8, one u32 per texel, 8x8-texel tiles (64 consecutive u32 = 256 B per tile)
+//   tex_info  [n_tex]     {width, height, tiles_per_row, first_texel}
+//   bvh nodes [n_nodes]   32 B each, see DevBvhNode (2 per 64-B line)
+#pragma once
+#include <stdint.h>
+
+#define RT_T_MIN 0.001f      /* raytracer_core/src/shapes/ray.rs:5 */
+#define RT_T_MAX 100000.0f   /* raytracer_core/src/shapes/ray.rs:6 */
+
+struct rt_f4 { float x, y, z, w; };
+
+// material record: 3 x 16 B
+struct DevMaterial {
+    float tr, tg, tb;      // throughput multiplier albedo/pi*3  (lambertian_diffuse.rs:60-65, metal.rs:51-55, dielectric.rs:61-65)
+    float param;           // METAL fuzziness | DIELECTRIC ior | TEXTURE scale
+    uint32_t kind;         // RTHIP_MAT_*
+    uint32_t texture;      // texture index
+    float shininess;       // ext: Phong exponent
+    float r1;              // DIELECTRIC: ((1-ior)/(1+ior))^2   dielectric.rs:48-49
+    float ar, ag, ab;      // albedo/pi (direct-light term of the point-light extension)
+    float inv_ior;         // DIELECTRIC: 1/ior  dielectric.rs:81
+};
+
+struct DevTexInfo {
+    uint32_t width, height;
+    uint32_t tiles_per_row;  // ceil(width/8)
+    uint32_t first_texel;    // offset into texels (in u32)
+};
+
+struct DevLight { float px, py, pz, _p0, ir, ig, ib, _p1; };
+
+// Linear BVH node, 32 B. Leaf iff count > 0: prims [first, first+count) of the BVH-ordered
+// primitive index array; inner: left child = node index + 1 (depth-first layout), right child = `first`.
+struct DevBvhNode {
+    float lo[3];
+    uint32_t first;
+    float hi[3];
+    uint32_t count;
+};
+
+struct KernelParams {
+    // camera (camera.rs:43-50)
+    float ox, oy, oz;
+    float d00x, d00y, d00z;
+    float hx, hy, hz;
+    float vx, vy, vz;
+    float inv_wm1, inv_hm1;  // 1/(width-1), 1/(height-1)   lib.rs:283,285
+    float inv_nb;            // 1/nb_samples                lib.rs:294
+    uint32_t width, height;
+    uint32_t spp, max_depth, seed, sample0, flags;
+    uint32_t band_rows, band_first, band_stride, owned_rows;
+    uint32_t accumulate;  // add the prior running sum (lib.rs:289-291)
+    // scene
+    uint32_t n_spheres, n_planes, n_tris, n_lights, n_bvh_nodes;
+    uint32_t n_bvh_spheres;  // BVH prim ids < n_bvh_spheres are spheres, the rest triangles (id - n_bvh_spheres)
+    const rt_f4 *sph_geom;
+    const rt_f4 *sph_shade;
+    const rt_f4 *pln_geom;
+    const rt_f4 *tri_geom;
+    const DevMaterial *materials;
+    const uint32_t *texels;
+    const DevTexInfo *tex_info;
+    const DevLight *lights;
+    const DevBvhNode *bvh_nodes;
+    const uint32_t *bvh_prims;
+    // outputs
+    float *accum;        // context-owned running sum, owned_rows*width*3
+    float *accum_out;    // optional caller copy (may be null)
+    uint32_t *rgba8;     // optional, owned_rows*width (R | G<<8 | B<<16 | 255<<24)
+    unsigned long long *stats;  // RT_STAT_* counters, RT_STAT_SHARDS shards of RT_STAT_N
+};
+
+enum { RT_STAT_PATHS = 0, RT_STAT_RAYS = 1, RT_STAT_SPHERE = 2, RT_STAT_PLANE = 3, RT_STAT_TRI = 4, RT_STAT_NODE = 5, RT_STAT_N = 8 };
+#define RT_STAT_SHARDS 64

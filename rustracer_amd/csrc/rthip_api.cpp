@@ -1,0 +1,545 @@
+// rthip_api.cpp — host side of the C ABI declared in include/rthip.h: context, scene flattening
+// (Scene = Vec<Box<dyn Shape>> -> SoA device buffers), camera upload, render-pass launch,
+// running-sum bookkeeping (PixelCache.incremental_raw_light / nb_samples, lib.rs:67-73,289-294).
+// No exception leaves an entry point.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rthip.h"
+#include "rt_bvh.h"
+#include "rt_device.h"
+
+extern "C" hipError_t rt_launch_render(const KernelParams *P, int count_stats, hipStream_t stream);
+extern "C" hipError_t rt_launch_pick(const KernelParams *P, float u, float v, long long *d_out, hipStream_t stream);
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace
+
+struct rthip_ctx {
+    int device = 0;
+    std::string err;
+    DevBuf sph_geom, sph_shade, pln_geom, tri_geom, materials, texels, tex_info, lights, bvh_nodes, bvh_prims;
+    DevBuf stats, accum, staging_rgba, staging_accum, pick_out;
+    KernelParams base;
+    bool have_scene = false, have_camera = false;
+    rthip_camera camera;
+    // running-sum state (lib.rs:67-73)
+    uint64_t nb_samples = 0;
+    uint32_t acc_width = 0, acc_height = 0, acc_rows = 0, acc_band_rows = 0, acc_band_first = 0, acc_band_stride = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr;  // used by the synchronous entry points
+    uint64_t n_shapes = 0;
+};
+
+namespace {
+
+thread_local std::string g_err;  // errors with no context (create failures)
+
+int fail(rthip_ctx *ctx, int status, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    g_err = msg;
+    return status;
+}
+
+#define HIPCHK(ctx, call)                                                                                      \
+    do {                                                                                                       \
+        hipError_t e__ = (call);                                                                               \
+        if (e__ != hipSuccess)                                                                                 \
+            return fail(ctx, e__ == hipErrorOutOfMemory ? RTHIP_E_OOM : RTHIP_E_HIP,                           \
+                        std::string(#call) + ": " + hipGetErrorString(e__));                                  \
+    } while (0)
+
+int upload(rthip_ctx *ctx, DevBuf &b, const void *src, size_t bytes) {
+    if (bytes > b.bytes || (bytes == 0 && b.p)) {
+        b.release();
+        if (bytes) {
+            HIPCHK(ctx, hipMalloc(&b.p, bytes));
+            b.bytes = bytes;
+        }
+    }
+    if (bytes) HIPCHK(ctx, hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return RTHIP_OK;
+}
+
+int ensure(rthip_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes > b.bytes) {
+        b.release();
+        HIPCHK(ctx, hipMalloc(&b.p, bytes));
+        b.bytes = bytes;
+    }
+    return RTHIP_OK;
+}
+
+inline rt_f4 f4(double x, double y, double z, double w) { return rt_f4{float(x), float(y), float(z), float(w)}; }
+inline float bits_f(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+struct D3 {
+    double x, y, z;
+};
+inline D3 d3(const double *p) { return D3{p[0], p[1], p[2]}; }
+inline D3 sub(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline D3 mul(D3 a, double s) { return D3{a.x * s, a.y * s, a.z * s}; }
+inline double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline D3 cross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline D3 normalize(D3 a) { return mul(a, 1.0 / std::sqrt(dot(a, a))); }
+
+bool finite3(const double *p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
+
+int owned_rows(const rthip_render_params *p, uint32_t *rows) {
+    if (!p || !rows) return RTHIP_E_BADARG;
+    if (p->band_rows == 0) {
+        *rows = p->height;
+        return RTHIP_OK;
+    }
+    if (p->band_stride == 0) return RTHIP_E_BADARG;
+    const uint64_t nbands = (uint64_t(p->height) + p->band_rows - 1) / p->band_rows;
+    uint64_t r = 0;
+    for (uint64_t b = p->band_first; b < nbands; b += p->band_stride) {
+        uint64_t lo = b * p->band_rows, hi = lo + p->band_rows;
+        if (hi > p->height) hi = p->height;
+        r += hi - lo;
+    }
+    *rows = uint32_t(r);
+    return RTHIP_OK;
+}
+
+int validate_params(rthip_ctx *ctx, const rthip_render_params *p) {
+    if (!p) return fail(ctx, RTHIP_E_BADARG, "params is NULL");
+    if (p->width < 2 || p->height < 2) return fail(ctx, RTHIP_E_BADARG, "width and height must be >= 2 (the jitter divides by width-1, height-1: lib.rs:283,285)");
+    if (p->width > 65536 || p->height > 65536) return fail(ctx, RTHIP_E_BADARG, "width/height above 65536 are not supported");
+    if (p->spp == 0) return fail(ctx, RTHIP_E_BADARG, "spp must be >= 1");
+    if (p->band_rows != 0 && p->band_stride == 0) return fail(ctx, RTHIP_E_BADARG, "band_stride must be >= 1 when band_rows != 0");
+    if (p->flags & ~uint32_t(RTHIP_F_ACCUMULATE | RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_NO_BVH))
+        return fail(ctx, RTHIP_E_BADARG, "unknown flag bits");
+    for (int i = 0; i < 7; i++)
+        if (p->reserved[i] != 0) return fail(ctx, RTHIP_E_BADARG, "reserved fields must be 0");
+    return RTHIP_OK;
+}
+
+void fill_camera(KernelParams &k, const rthip_camera &c) {
+    k.ox = float(c.origin[0]), k.oy = float(c.origin[1]), k.oz = float(c.origin[2]);
+    k.d00x = float(c.d00[0]), k.d00y = float(c.d00[1]), k.d00z = float(c.d00[2]);
+    k.hx = float(c.horizontal[0]), k.hy = float(c.horizontal[1]), k.hz = float(c.horizontal[2]);
+    k.vx = float(c.vertical[0]), k.vy = float(c.vertical[1]), k.vz = float(c.vertical[2]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rthip_abi_version(void) { return RTHIP_ABI_VERSION; }
+
+const char *rthip_status_string(int status) {
+    switch (status) {
+        case RTHIP_OK: return "ok";
+        case RTHIP_E_BADARG: return "bad argument";
+        case RTHIP_E_HIP: return "HIP runtime error";
+        case RTHIP_E_OOM: return "out of device memory";
+        case RTHIP_E_NODEVICE: return "no such device";
+        case RTHIP_E_STATE: return "call order / state error";
+        case RTHIP_E_INTERNAL: return "internal error";
+        default: return "unknown status";
+    }
+}
+
+const char *rthip_last_error(const rthip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int rthip_device_count(int *out_count) {
+    if (!out_count) return RTHIP_E_BADARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out_count = 0;
+        return fail(nullptr, e == hipErrorNoDevice ? RTHIP_E_NODEVICE : RTHIP_E_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *out_count = n;
+    return RTHIP_OK;
+}
+
+int rthip_camera_lookat(double x, double y, double z, const double lookat[3], rthip_camera *out) {
+    // Camera::new_lookat — camera.rs:19-41 (fov 20 "degrees" used as 2*radians(20), 16:9 viewport regardless of image size)
+    if (!lookat || !out) return RTHIP_E_BADARG;
+    const double PI = 3.14159265358979323846264338327950288;
+    D3 origin{x, y, z}, la = d3(lookat), vup{0.0, 1.0, 0.0};
+    const double viewport_height = 2.0 * (20.0 * (PI / 180.0));
+    const double viewport_width = (16.0 / 9.0) * viewport_height;
+    D3 w = normalize(sub(origin, la));
+    D3 u = normalize(cross(vup, w));
+    D3 v = cross(w, u);
+    D3 H = mul(u, viewport_width), V = mul(v, viewport_height);
+    // lower_left_corner = origin - H/2 - V/2 - w ; d00 = lower_left_corner - origin
+    D3 llc = sub(sub(sub(origin, mul(H, 0.5)), mul(V, 0.5)), w);
+    D3 d00 = sub(llc, origin);
+    out->origin[0] = origin.x, out->origin[1] = origin.y, out->origin[2] = origin.z;
+    out->d00[0] = d00.x, out->d00[1] = d00.y, out->d00[2] = d00.z;
+    out->horizontal[0] = H.x, out->horizontal[1] = H.y, out->horizontal[2] = H.z;
+    out->vertical[0] = V.x, out->vertical[1] = V.y, out->vertical[2] = V.z;
+    return RTHIP_OK;
+}
+
+int rthip_owned_rows(const rthip_render_params *params, uint32_t *out_rows) { return owned_rows(params, out_rows); }
+
+int rthip_create(int device, rthip_ctx **out_ctx) {
+    if (!out_ctx) return RTHIP_E_BADARG;
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(nullptr, RTHIP_E_NODEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(nullptr, RTHIP_E_NODEVICE, "device index out of range");
+    rthip_ctx *ctx = new (std::nothrow) rthip_ctx();
+    if (!ctx) return RTHIP_E_OOM;
+    ctx->device = device;
+    std::memset(&ctx->base, 0, sizeof ctx->base);
+    int st = [&]() -> int {
+        HIPCHK(ctx, hipSetDevice(device));
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreate(&ctx->ev0));
+        HIPCHK(ctx, hipEventCreate(&ctx->ev1));
+        HIPCHK(ctx, hipMalloc(&ctx->stats.p, RT_STAT_SHARDS * RT_STAT_N * sizeof(unsigned long long)));
+        ctx->stats.bytes = RT_STAT_SHARDS * RT_STAT_N * sizeof(unsigned long long);
+        HIPCHK(ctx, hipMalloc(&ctx->pick_out.p, sizeof(long long)));
+        ctx->pick_out.bytes = sizeof(long long);
+        return RTHIP_OK;
+    }();
+    if (st != RTHIP_OK) {
+        g_err = ctx->err;
+        rthip_destroy(ctx);
+        return st;
+    }
+    *out_ctx = ctx;
+    return RTHIP_OK;
+}
+
+void rthip_destroy(rthip_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf *b : {&ctx->sph_geom, &ctx->sph_shade, &ctx->pln_geom, &ctx->tri_geom, &ctx->materials, &ctx->texels, &ctx->tex_info, &ctx->lights,
+                      &ctx->bvh_nodes, &ctx->bvh_prims, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out})
+        b->release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
+    if (!ctx) return RTHIP_E_BADARG;
+    if (!s) return fail(ctx, RTHIP_E_BADARG, "scene is NULL");
+    try {
+        if ((s->n_spheres && !s->spheres) || (s->n_planes && !s->planes) || (s->n_triangles && !s->triangles) ||
+            (s->n_materials && !s->materials) || (s->n_textures && !s->textures) || (s->n_lights && !s->lights))
+            return fail(ctx, RTHIP_E_BADARG, "a non-empty array has a NULL pointer");
+        const uint64_t n_shapes = s->n_spheres + s->n_planes + s->n_triangles;
+        if (n_shapes >= 0x7fffffffull) return fail(ctx, RTHIP_E_BADARG, "too many shapes");
+        if (s->n_materials >= 0x7fffffffull || s->n_textures >= 0x7fffffffull || s->n_lights > 1024)
+            return fail(ctx, RTHIP_E_BADARG, "too many materials/textures/lights");
+        // ---- validate ----
+        for (uint64_t i = 0; i < s->n_materials; i++) {
+            const rthip_material &m = s->materials[i];
+            if (m.kind > RTHIP_MAT_TEXTURE) return fail(ctx, RTHIP_E_BADARG, "material " + std::to_string(i) + ": unknown kind");
+            if (m.kind == RTHIP_MAT_TEXTURE && m.texture >= s->n_textures)
+                return fail(ctx, RTHIP_E_BADARG, "material " + std::to_string(i) + ": texture index out of range");
+        }
+        for (uint64_t i = 0; i < s->n_textures; i++) {
+            const rthip_texture &t = s->textures[i];
+            if (!t.rgb8 || t.width == 0 || t.height == 0 || t.width > 32768 || t.height > 32768)
+                return fail(ctx, RTHIP_E_BADARG, "texture " + std::to_string(i) + ": bad size or NULL texels");
+        }
+        for (uint64_t i = 0; i < s->n_spheres; i++) {
+            if (s->spheres[i].material >= s->n_materials) return fail(ctx, RTHIP_E_BADARG, "sphere " + std::to_string(i) + ": material index out of range");
+            if (!finite3(s->spheres[i].center) || !std::isfinite(s->spheres[i].radius) || s->spheres[i].radius == 0.0)
+                return fail(ctx, RTHIP_E_BADARG, "sphere " + std::to_string(i) + ": non-finite centre or zero/non-finite radius");
+        }
+        for (uint64_t i = 0; i < s->n_planes; i++) {
+            if (s->planes[i].material >= s->n_materials) return fail(ctx, RTHIP_E_BADARG, "plane " + std::to_string(i) + ": material index out of range");
+            D3 n = d3(s->planes[i].normal);
+            if (!finite3(s->planes[i].point) || !finite3(s->planes[i].normal) || dot(n, n) == 0.0)
+                return fail(ctx, RTHIP_E_BADARG, "plane " + std::to_string(i) + ": bad point/normal");
+        }
+        for (uint64_t i = 0; i < s->n_triangles; i++) {
+            if (s->triangles[i].material >= s->n_materials) return fail(ctx, RTHIP_E_BADARG, "triangle " + std::to_string(i) + ": material index out of range");
+            if (!finite3(s->triangles[i].v0) || !finite3(s->triangles[i].v1) || !finite3(s->triangles[i].v2))
+                return fail(ctx, RTHIP_E_BADARG, "triangle " + std::to_string(i) + ": non-finite vertex");
+        }
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->have_scene = false;
+        const double PI = 3.14159265358979323846264338327950288;
+
+        // ---- spheres: geom {c, r^2}, shade {1/r, material} ----
+        std::vector<rt_f4> geom(s->n_spheres), shade(s->n_spheres);
+        for (uint64_t i = 0; i < s->n_spheres; i++) {
+            const rthip_sphere &sp = s->spheres[i];
+            geom[i] = f4(sp.center[0], sp.center[1], sp.center[2], sp.radius * sp.radius);
+            shade[i] = rt_f4{float(1.0 / sp.radius), bits_f(sp.material), float(sp.radius), 0.0f};
+        }
+        int st;
+        if ((st = upload(ctx, ctx->sph_geom, geom.data(), geom.size() * sizeof(rt_f4)))) return st;
+        if ((st = upload(ctx, ctx->sph_shade, shade.data(), shade.size() * sizeof(rt_f4)))) return st;
+        // ---- planes: {n, n.p0} {p0, material} {tu} {tv} ----
+        std::vector<rt_f4> pl(4 * s->n_planes);
+        for (uint64_t i = 0; i < s->n_planes; i++) {
+            const rthip_plane &p = s->planes[i];
+            D3 n = normalize(d3(p.normal)), p0 = d3(p.point);
+            D3 a = std::fabs(n.x) > 0.9 ? D3{0, 1, 0} : D3{1, 0, 0};
+            D3 tu = normalize(cross(a, n)), tv = cross(n, tu);
+            pl[4 * i + 0] = f4(n.x, n.y, n.z, dot(n, p0));
+            pl[4 * i + 1] = rt_f4{float(p0.x), float(p0.y), float(p0.z), bits_f(p.material)};
+            pl[4 * i + 2] = f4(tu.x, tu.y, tu.z, 0);
+            pl[4 * i + 3] = f4(tv.x, tv.y, tv.z, 0);
+        }
+        if ((st = upload(ctx, ctx->pln_geom, pl.data(), pl.size() * sizeof(rt_f4)))) return st;
+        // ---- triangles: {v0, material} {e1} {e2} ----
+        std::vector<rt_f4> tr(3 * s->n_triangles);
+        for (uint64_t i = 0; i < s->n_triangles; i++) {
+            const rthip_triangle &t = s->triangles[i];
+            // edges are differences of the FLOAT vertices so that the device sees exactly the float triangle
+            float v0[3] = {float(t.v0[0]), float(t.v0[1]), float(t.v0[2])};
+            float v1[3] = {float(t.v1[0]), float(t.v1[1]), float(t.v1[2])};
+            float v2[3] = {float(t.v2[0]), float(t.v2[1]), float(t.v2[2])};
+            tr[3 * i + 0] = rt_f4{v0[0], v0[1], v0[2], bits_f(t.material)};
+            tr[3 * i + 1] = rt_f4{v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2], 0.0f};
+            tr[3 * i + 2] = rt_f4{v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.0f};
+        }
+        if ((st = upload(ctx, ctx->tri_geom, tr.data(), tr.size() * sizeof(rt_f4)))) return st;
+        // ---- materials ----
+        std::vector<DevMaterial> mats(s->n_materials);
+        for (uint64_t i = 0; i < s->n_materials; i++) {
+            const rthip_material &m = s->materials[i];
+            DevMaterial &d = mats[i];
+            std::memset(&d, 0, sizeof d);
+            // constructors store albedo/PI (lambertian_diffuse.rs:21, metal.rs:21, dielectric.rs:22); scatter multiplies by 3.0
+            d.ar = float(m.albedo[0] / PI), d.ag = float(m.albedo[1] / PI), d.ab = float(m.albedo[2] / PI);
+            d.tr = float(m.albedo[0] / PI * 3.0), d.tg = float(m.albedo[1] / PI * 3.0), d.tb = float(m.albedo[2] / PI * 3.0);
+            d.param = float(m.param);
+            d.kind = m.kind;
+            d.texture = m.texture;
+            d.shininess = float(m.shininess);
+            if (m.kind == RTHIP_MAT_DIELECTRIC) {
+                double r0 = (1.0 - m.param) / (1.0 + m.param);  // dielectric.rs:48
+                d.r1 = float(r0 * r0);
+                d.inv_ior = float(1.0 / m.param);  // dielectric.rs:81
+            }
+        }
+        if ((st = upload(ctx, ctx->materials, mats.data(), mats.size() * sizeof(DevMaterial)))) return st;
+        // ---- textures: RGB8 -> RGBA8 in 8x8-texel tiles (a wave's nearby UVs touch few 256-B tiles) ----
+        std::vector<DevTexInfo> ti(s->n_textures);
+        size_t total_texels = 0;
+        for (uint64_t i = 0; i < s->n_textures; i++) {
+            const rthip_texture &t = s->textures[i];
+            ti[i].width = t.width, ti[i].height = t.height;
+            ti[i].tiles_per_row = (t.width + 7) / 8;
+            if (total_texels > 0xffffffffull) return fail(ctx, RTHIP_E_BADARG, "textures exceed 2^32 texels");
+            ti[i].first_texel = uint32_t(total_texels);
+            total_texels += size_t(ti[i].tiles_per_row) * ((t.height + 7) / 8) * 64;
+        }
+        if (total_texels > 0xffffffffull) return fail(ctx, RTHIP_E_BADARG, "textures exceed 2^32 texels");
+        std::vector<uint32_t> texels(total_texels, 0u);
+        for (uint64_t i = 0; i < s->n_textures; i++) {
+            const rthip_texture &t = s->textures[i];
+            for (uint32_t y = 0; y < t.height; y++)
+                for (uint32_t x = 0; x < t.width; x++) {
+                    const uint8_t *px = t.rgb8 + (size_t(y) * t.width + x) * 3;
+                    size_t idx = size_t(ti[i].first_texel) + ((size_t(y >> 3) * ti[i].tiles_per_row + (x >> 3)) << 6) + ((y & 7u) << 3) + (x & 7u);
+                    texels[idx] = uint32_t(px[0]) | (uint32_t(px[1]) << 8) | (uint32_t(px[2]) << 16) | 0xff000000u;
+                }
+        }
+        if ((st = upload(ctx, ctx->texels, texels.data(), texels.size() * sizeof(uint32_t)))) return st;
+        if ((st = upload(ctx, ctx->tex_info, ti.data(), ti.size() * sizeof(DevTexInfo)))) return st;
+        // ---- lights ----
+        std::vector<DevLight> lights(s->n_lights);
+        for (uint64_t i = 0; i < s->n_lights; i++) {
+            const rthip_light &l = s->lights[i];
+            lights[i] = DevLight{float(l.position[0]), float(l.position[1]), float(l.position[2]), 0.0f,
+                                 float(l.intensity[0]), float(l.intensity[1]), float(l.intensity[2]), 0.0f};
+        }
+        if ((st = upload(ctx, ctx->lights, lights.data(), lights.size() * sizeof(DevLight)))) return st;
+        // ---- linear BVH over spheres + triangles for big scenes ----
+        std::vector<DevBvhNode> nodes;
+        std::vector<uint32_t> prims;
+        if (s->n_spheres + s->n_triangles > RT_BVH_THRESHOLD) rt_build_bvh(s, nodes, prims);
+        if ((st = upload(ctx, ctx->bvh_nodes, nodes.data(), nodes.size() * sizeof(DevBvhNode)))) return st;
+        if ((st = upload(ctx, ctx->bvh_prims, prims.data(), prims.size() * sizeof(uint32_t)))) return st;
+
+        KernelParams &k = ctx->base;
+        k.n_spheres = uint32_t(s->n_spheres), k.n_planes = uint32_t(s->n_planes), k.n_tris = uint32_t(s->n_triangles);
+        k.n_lights = uint32_t(s->n_lights);
+        k.n_bvh_nodes = uint32_t(nodes.size());
+        k.n_bvh_spheres = uint32_t(s->n_spheres);
+        k.sph_geom = (const rt_f4 *)ctx->sph_geom.p, k.sph_shade = (const rt_f4 *)ctx->sph_shade.p;
+        k.pln_geom = (const rt_f4 *)ctx->pln_geom.p, k.tri_geom = (const rt_f4 *)ctx->tri_geom.p;
+        k.materials = (const DevMaterial *)ctx->materials.p;
+        k.texels = (const uint32_t *)ctx->texels.p, k.tex_info = (const DevTexInfo *)ctx->tex_info.p;
+        k.lights = (const DevLight *)ctx->lights.p;
+        k.bvh_nodes = (const DevBvhNode *)ctx->bvh_nodes.p, k.bvh_prims = (const uint32_t *)ctx->bvh_prims.p;
+        ctx->n_shapes = n_shapes;
+        ctx->have_scene = true;
+        ctx->nb_samples = 0;  // a new scene invalidates the running sum
+        return RTHIP_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, RTHIP_E_OOM, "host allocation failed while flattening the scene");
+    } catch (...) {
+        return fail(ctx, RTHIP_E_INTERNAL, "unexpected exception in rthip_upload_scene");
+    }
+}
+
+int rthip_set_camera(rthip_ctx *ctx, const rthip_camera *camera) {
+    if (!ctx) return RTHIP_E_BADARG;
+    if (!camera) return fail(ctx, RTHIP_E_BADARG, "camera is NULL");
+    if (!finite3(camera->origin) || !finite3(camera->d00) || !finite3(camera->horizontal) || !finite3(camera->vertical))
+        return fail(ctx, RTHIP_E_BADARG, "camera has non-finite components");
+    ctx->camera = *camera;
+    fill_camera(ctx->base, *camera);
+    ctx->have_camera = true;
+    ctx->nb_samples = 0;  // standalone/src/main.rs:103-120: a camera command invalidates the pixels
+    return RTHIP_OK;
+}
+
+int rthip_reset_accum(rthip_ctx *ctx) {
+    if (!ctx) return RTHIP_E_BADARG;
+    ctx->nb_samples = 0;
+    return RTHIP_OK;
+}
+
+int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgba8, void *d_accum, void *hip_stream, rthip_stats *stats) {
+    if (!ctx) return RTHIP_E_BADARG;
+    try {
+        int st = validate_params(ctx, p);
+        if (st) return st;
+        if (!ctx->have_scene) return fail(ctx, RTHIP_E_STATE, "rthip_upload_scene has not been called");
+        if (!ctx->have_camera) return fail(ctx, RTHIP_E_STATE, "rthip_set_camera has not been called");
+        uint32_t rows = 0;
+        if ((st = owned_rows(p, &rows))) return fail(ctx, st, "bad band parameters");
+        if ((p->flags & RTHIP_F_POINT_LIGHTS) && ctx->base.n_lights == 0) return fail(ctx, RTHIP_E_STATE, "RTHIP_F_POINT_LIGHTS without lights in the scene");
+        hipStream_t stream = (hipStream_t)hip_stream;
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        const bool same_layout = ctx->acc_width == p->width && ctx->acc_height == p->height && ctx->acc_rows == rows &&
+                                 ctx->acc_band_rows == p->band_rows && ctx->acc_band_first == p->band_first && ctx->acc_band_stride == p->band_stride;
+        const bool accumulate = (p->flags & RTHIP_F_ACCUMULATE) && ctx->nb_samples > 0;
+        if (accumulate && !same_layout) return fail(ctx, RTHIP_E_STATE, "RTHIP_F_ACCUMULATE with a different image/band layout than the running sum");
+        const uint64_t prior = accumulate ? ctx->nb_samples : 0;
+        if (prior + p->spp > 0xffffffffull) return fail(ctx, RTHIP_E_BADARG, "more than 2^32 samples per pixel");
+        if (rows == 0) {
+            if (stats) std::memset(stats, 0, sizeof *stats);
+            return RTHIP_OK;
+        }
+        if ((st = ensure(ctx, ctx->accum, size_t(rows) * p->width * 3 * sizeof(float)))) return st;
+
+        KernelParams k = ctx->base;
+        k.width = p->width, k.height = p->height;
+        k.inv_wm1 = float(1.0 / (double(p->width) - 1.0));
+        k.inv_hm1 = float(1.0 / (double(p->height) - 1.0));
+        k.spp = p->spp, k.max_depth = p->max_depth, k.seed = p->seed;
+        k.sample0 = uint32_t(prior);
+        k.flags = p->flags;
+        k.band_rows = p->band_rows, k.band_first = p->band_first, k.band_stride = p->band_stride, k.owned_rows = rows;
+        k.accumulate = accumulate ? 1u : 0u;
+        k.inv_nb = float(1.0 / double(prior + p->spp));
+        k.accum = (float *)ctx->accum.p;
+        k.accum_out = (float *)d_accum;
+        k.rgba8 = (uint32_t *)d_rgba8;
+        k.stats = (unsigned long long *)ctx->stats.p;
+        if (p->flags & RTHIP_F_NO_BVH) k.n_bvh_nodes = 0;
+
+        HIPCHK(ctx, hipMemsetAsync(ctx->stats.p, 0, ctx->stats.bytes, stream));
+        if (stats) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
+        HIPCHK(ctx, rt_launch_render(&k, (p->flags & RTHIP_F_COUNT_STATS) ? 1 : 0, stream));
+        if (stats) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
+
+        ctx->acc_width = p->width, ctx->acc_height = p->height, ctx->acc_rows = rows;
+        ctx->acc_band_rows = p->band_rows, ctx->acc_band_first = p->band_first, ctx->acc_band_stride = p->band_stride;
+        ctx->nb_samples = prior + p->spp;
+
+        if (stats) {
+            std::memset(stats, 0, sizeof *stats);
+            unsigned long long h[RT_STAT_SHARDS * RT_STAT_N];
+            HIPCHK(ctx, hipMemcpyAsync(h, ctx->stats.p, sizeof h, hipMemcpyDeviceToHost, stream));
+            HIPCHK(ctx, hipStreamSynchronize(stream));
+            float ms = 0.0f;
+            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            for (int sh = 0; sh < RT_STAT_SHARDS; sh++) {
+                stats->paths += h[sh * RT_STAT_N + RT_STAT_PATHS];
+                stats->rays += h[sh * RT_STAT_N + RT_STAT_RAYS];
+                stats->sphere_tests += h[sh * RT_STAT_N + RT_STAT_SPHERE];
+                stats->plane_tests += h[sh * RT_STAT_N + RT_STAT_PLANE];
+                stats->tri_tests += h[sh * RT_STAT_N + RT_STAT_TRI];
+                stats->node_tests += h[sh * RT_STAT_N + RT_STAT_NODE];
+            }
+            stats->rows = rows;
+            stats->nb_samples = ctx->nb_samples;
+            stats->kernel_ms = ms;
+        }
+        return RTHIP_OK;
+    } catch (...) {
+        return fail(ctx, RTHIP_E_INTERNAL, "unexpected exception in rthip_render_device");
+    }
+}
+
+int rthip_render(rthip_ctx *ctx, const rthip_render_params *p, uint8_t *rgba8_out, float *accum_out, rthip_stats *stats) {
+    if (!ctx) return RTHIP_E_BADARG;
+    try {
+        int st = validate_params(ctx, p);
+        if (st) return st;
+        uint32_t rows = 0;
+        if ((st = owned_rows(p, &rows))) return fail(ctx, st, "bad band parameters");
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        const size_t npx = size_t(rows) * p->width;
+        if (rgba8_out && npx && (st = ensure(ctx, ctx->staging_rgba, npx * 4))) return st;
+        rthip_stats local;
+        st = rthip_render_device(ctx, p, (rgba8_out && npx) ? ctx->staging_rgba.p : nullptr, nullptr, ctx->stream, &local);
+        if (st) return st;
+        hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
+        HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+        if (rgba8_out && npx) HIPCHK(ctx, hipMemcpyAsync(rgba8_out, ctx->staging_rgba.p, npx * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (accum_out && npx) HIPCHK(ctx, hipMemcpyAsync(accum_out, ctx->accum.p, npx * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        float ms = 0.0f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+        local.d2h_ms = ms;
+        if (stats) *stats = local;
+        return RTHIP_OK;
+    } catch (...) {
+        return fail(ctx, RTHIP_E_INTERNAL, "unexpected exception in rthip_render");
+    }
+}
+
+int rthip_pick(rthip_ctx *ctx, uint32_t width, uint32_t height, double x, double y, int64_t *out_shape) {
+    if (!ctx) return RTHIP_E_BADARG;
+    if (!out_shape || width < 2 || height < 2) return fail(ctx, RTHIP_E_BADARG, "bad pick arguments");
+    if (!ctx->have_scene || !ctx->have_camera) return fail(ctx, RTHIP_E_STATE, "scene/camera not uploaded");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // lib.rs:263-265: emit_ray_at(x/(width-1), y/(height-1))
+    const float u = float(x / (double(width) - 1.0)), v = float(y / (double(height) - 1.0));
+    KernelParams k = ctx->base;
+    HIPCHK(ctx, rt_launch_pick(&k, u, v, (long long *)ctx->pick_out.p, ctx->stream));
+    long long r = -1;
+    HIPCHK(ctx, hipMemcpyAsync(&r, ctx->pick_out.p, sizeof r, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out_shape = r;
+    return RTHIP_OK;
+}
+
+}  // extern "C"
