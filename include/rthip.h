@@ -156,6 +156,9 @@ typedef struct rthip_stats {
     uint64_t plane_tests;
     uint64_t tri_tests;
     uint64_t node_tests;
+    uint64_t hits[4];      /* RTHIP_F_COUNT_STATS only: closest hits by material kind (RTHIP_MAT_*) */
+    uint64_t sky_evals;    /* RTHIP_F_COUNT_STATS only: background_color evaluations (ray.rs:89-93) */
+    uint64_t shadow_rays;  /* RTHIP_F_COUNT_STATS only: any-hit shadow segments (included in `rays`) */
     uint64_t rows;         /* rows rendered by this context this pass */
     uint64_t nb_samples;   /* samples accumulated per pixel so far (PixelCache.nb_samples, lib.rs:72) */
     double kernel_ms;      /* device time of the render kernel(s), HIP events */
@@ -213,6 +216,27 @@ int rthip_reset_accum(rthip_ctx *ctx);
 /* Raytracer::get_shape (lib.rs:262-267): un-jittered primary ray through pixel (x, y) of a
  * width x height image; *out_shape = index of the closest shape, or -1 for a miss. */
 int rthip_pick(rthip_ctx *ctx, uint32_t width, uint32_t height, double x, double y, int64_t *out_shape);
+
+/*
+ * Algorithmic FP32 flops of a pass, from the counters of an RTHIP_F_COUNT_STATS run and the
+ * per-operation constants RTHIP_FLOPS_* below (+,-,*,/,sqrt,min/max,compare-select = 1,
+ * FMA = 2, RNG integer work = 0). Used for the "% of FP32 VALU roofline" figure.
+ */
+double rthip_algorithmic_flops(const rthip_stats *stats);
+
+#define RTHIP_FLOPS_RAY_SETUP 16.0    /* per path: u,v (4) + direction (12)            lib.rs:282-286, camera.rs:43-50 */
+#define RTHIP_FLOPS_SEGMENT 5.0       /* per segment: a = d.d                          sphere.rs:31 */
+#define RTHIP_FLOPS_SPHERE_TEST 18.0  /* oc 3, half_b 5, c 7, discriminant 3           sphere.rs:30-34 */
+#define RTHIP_FLOPS_PLANE_TEST 11.0   /* extension */
+#define RTHIP_FLOPS_TRI_TEST 48.0     /* extension: Moller-Trumbore */
+#define RTHIP_FLOPS_NODE_TEST 24.0    /* extension: AABB slab test */
+#define RTHIP_FLOPS_HIT 19.0          /* sqrt + 2 roots 7, ray.at 6, normal 6          sphere.rs:37-65 */
+#define RTHIP_FLOPS_SKY 20.0          /* normalize + lerp                              ray.rs:89-93 */
+#define RTHIP_FLOPS_LAMBERTIAN 18.0   /* throughput 3, n + unit vector 12, sin/cos/sqrt 3   lambertian_diffuse.rs:39-73 */
+#define RTHIP_FLOPS_METAL 36.0        /* throughput 3, normalize+reflect+fuzz+test 30, sin/cos/sqrt 3   metal.rs:27-66 */
+#define RTHIP_FLOPS_DIELECTRIC 73.0   /* throughput 3, reflect/refract/schlick 70      dielectric.rs:28-98 */
+#define RTHIP_FLOPS_TEXTURE 15.0      /* throughput 3, uv + wrap 12 (atan2/acos = 1 each)   sphere.rs:67-73, texture.rs:32-57 */
+#define RTHIP_FLOPS_TONEMAP 12.0      /* per pixel: 4 per channel                      lib.rs:294-298 */
 
 const char *rthip_last_error(const rthip_ctx *ctx);
 const char *rthip_status_string(int status);

@@ -126,4 +126,28 @@ void oracle_project_ray(const rthip_scene_desc *scene, const double origin[3], c
     if (segments) *segments = st.rays;
 }
 
+// debug: trace the hit sequence of path (x, y, sample) in either precision; returns the number of segments
+int oracle_trace_path(const rthip_scene_desc *scene, const rthip_camera *cam, const rthip_render_params *p, uint32_t x, uint32_t y,
+                      uint32_t sample, int precision, int64_t *shapes, double *ts, double *dlens, double rgb[3]) {
+    PathTrace tr;
+    g_trace = &tr;
+    const uint32_t key = path_key(p->seed, y * p->width + x, sample);
+    if (precision == 64) {
+        Scene<double> s(*scene);
+        double ox = (double(x) + rng_unit<double>(key, 0)) / (double(p->width) - 1.0);
+        double oy = (double(y) + rng_unit<double>(key, 1)) / (double(p->height) - 1.0);
+        V3<double> c = project_ray<double>(s, emit_ray_at<double>(*cam, ox, oy), p->max_depth, key, false, nullptr);
+        rgb[0] = c.x, rgb[1] = c.y, rgb[2] = c.z;
+    } else {
+        Scene<float> s(*scene);
+        float ox = (float(x) + rng_unit<float>(key, 0)) / (float(p->width) - 1.0f);
+        float oy = (float(y) + rng_unit<float>(key, 1)) / (float(p->height) - 1.0f);
+        V3<float> c = project_ray<float>(s, emit_ray_at<float>(*cam, ox, oy), p->max_depth, key, false, nullptr);
+        rgb[0] = c.x, rgb[1] = c.y, rgb[2] = c.z;
+    }
+    g_trace = nullptr;
+    for (int i = 0; i < tr.n; i++) shapes[i] = tr.shape[i], ts[i] = tr.t[i], dlens[i] = tr.dlen[i];
+    return tr.n;
+}
+
 }  // extern "C"

@@ -311,6 +311,7 @@ struct Scene {
         const Real t_min = Consts<Real>::T_MIN, t_max = Real(1.0);
         if (st) {
             st->rays++;
+            st->shadow_rays++;
             st->sphere_tests += spheres.size();
             st->plane_tests += planes.size();
             st->tri_tests += tris.size();
@@ -405,6 +406,15 @@ static inline bool refract(const V3<Real> &ray, const V3<Real> &normal, Real ref
 //   bounce None -> T (the surface colour is returned as is, ray.rs:80); else continue.
 //   After max_depth segments: T*sky(next ray) (ray.rs:70-72: depth exhaustion returns sky).
 // ----------------------------------------------------------------------------------------
+// optional per-path trace (debug aid for tests/tools): hit shape and t of each segment
+struct PathTrace {
+    int n = 0;
+    int64_t shape[64];
+    double t[64];
+    double dlen[64];
+};
+static thread_local PathTrace *g_trace = nullptr;
+
 template <class Real>
 static inline V3<Real> mulv(const V3<Real> &a, const V3<Real> &b) { return V3<Real>(a.x * b.x, a.y * b.y, a.z * b.z); }  // blend, ray.rs:14-18
 
@@ -419,10 +429,24 @@ static V3<Real> project_ray(const Scene<Real> &scene, Ray<Real> ray, uint32_t ma
     Vec T(1, 1, 1);
     Vec Ldirect(0, 0, 0);  // extension: accumulated direct light (point-light mode)
     for (uint32_t bounce = 0;; bounce++) {
-        if (bounce == max_depth) return Ldirect + mulv(T, background_color(ray));  // ray.rs:70-72
+        if (bounce == max_depth) {  // ray.rs:70-72
+            if (st) st->sky_evals++;
+            return Ldirect + mulv(T, background_color(ray));
+        }
         Hit<Real> hit;
-        if (!scene.find_collision(ray, &hit, st)) return Ldirect + mulv(T, background_color(ray));  // ray.rs:85
+        const bool found = scene.find_collision(ray, &hit, st);
+        if (g_trace && g_trace->n < 64) {
+            g_trace->shape[g_trace->n] = found ? hit.shape : -1;
+            g_trace->t[g_trace->n] = found ? double(hit.t) : 0.0;
+            g_trace->dlen[g_trace->n] = std::sqrt(double(ray.direction.magnitude_squared()));
+            g_trace->n++;
+        }
+        if (!found) {  // ray.rs:85
+            if (st) st->sky_evals++;
+            return Ldirect + mulv(T, background_color(ray));
+        }
         const auto &m = scene.materials[scene.material_of(hit.shape)];
+        if (st) st->hits[m.kind]++;
         const uint32_t ctr = 2 + 2 * bounce;
         const Vec normal = scene.normal_at(hit);  // collision.rs:29-31
         const Real light_intensity = Real(3.0);   // "global lightning, to be changed"
@@ -575,6 +599,8 @@ static void render(const rthip_scene_desc &desc, const rthip_camera &cam, const 
         {
             total.paths += st.paths; total.rays += st.rays; total.sphere_tests += st.sphere_tests;
             total.plane_tests += st.plane_tests; total.tri_tests += st.tri_tests;
+            for (int k = 0; k < 4; k++) total.hits[k] += st.hits[k];
+            total.sky_evals += st.sky_evals; total.shadow_rays += st.shadow_rays;
         }
     }
     total.rows = ch;

@@ -73,10 +73,11 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("plane_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("node_tests", C.c_uint64),
+                ("hits", C.c_uint64 * 4), ("sky_evals", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("rows", C.c_uint64), ("nb_samples", C.c_uint64), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n == "hits" else getattr(self, n)) for n, _ in self._fields_}
 
 
 # every symbol include/rthip.h declares: name -> (restype, argtypes)
@@ -92,6 +93,7 @@ SYMBOLS = {
     "rthip_render_device": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]),
     "rthip_reset_accum": (C.c_int, [C.c_void_p]),
     "rthip_pick": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _P(C.c_int64)]),
+    "rthip_algorithmic_flops": (C.c_double, [_P(Stats)]),
     "rthip_last_error": (C.c_char_p, [C.c_void_p]),
     "rthip_status_string": (C.c_char_p, [C.c_int]),
     "rthip_abi_version": (C.c_int, []),

@@ -1,5 +1,178 @@
+// rt_bvh.cpp — host-side builder of the linear BVH used for big scenes (extension: the reference
+// scans every shape linearly, raytracer_core/src/shapes/ray.rs:47-67; the BVH must return exactly
+// what that scan returns, including the "later index wins on equal t" rule, see rt_kernels.hip).
+//
+// Binned-SAH top-down build over the FLOAT primitives the device will test (so the boxes bound what
+// the kernel intersects), leaves of <= RT_BVH_LEAF primitives, depth-first node order:
+// left child = node + 1, right child = node.first (inner nodes have count == 0).
+// Depth is capped at RT_BVH_MAX_DEPTH (the traversal stack lives in LDS) by switching to median
+// splits when a subtree could otherwise exceed it.
 #include "rt_bvh.h"
-void rt_build_bvh(const rthip_scene_desc *, std::vector<DevBvhNode> &nodes, std::vector<uint32_t> &prims) {
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() {
+        for (int k = 0; k < 3; k++) lo[k] = INFINITY, hi[k] = -INFINITY;
+    }
+    void grow(const Box &b) {
+        for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], b.lo[k]), hi[k] = std::max(hi[k], b.hi[k]);
+    }
+    void grow_pt(const float *p) {
+        for (int k = 0; k < 3; k++) lo[k] = std::min(lo[k], p[k]), hi[k] = std::max(hi[k], p[k]);
+    }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Builder {
+    std::vector<Box> pbox;       // per primitive
+    std::vector<float> centroid; // 3 per primitive
+    std::vector<uint32_t> &prims;
+    std::vector<DevBvhNode> &nodes;
+    Builder(std::vector<uint32_t> &p, std::vector<DevBvhNode> &n) : prims(p), nodes(n) {}
+
+    static constexpr int BINS = 16;
+
+    uint32_t build(uint32_t begin, uint32_t end, int depth) {
+        const uint32_t me = uint32_t(nodes.size());
+        nodes.emplace_back();
+        Box b, cb;
+        b.reset(), cb.reset();
+        for (uint32_t i = begin; i < end; i++) {
+            b.grow(pbox[prims[i]]);
+            cb.grow_pt(&centroid[3 * size_t(prims[i])]);
+        }
+        for (int k = 0; k < 3; k++) nodes[me].lo[k] = b.lo[k], nodes[me].hi[k] = b.hi[k];
+        const uint32_t n = end - begin;
+        if (n <= RT_BVH_LEAF) {
+            nodes[me].first = begin, nodes[me].count = n;
+            return me;
+        }
+        // pick the split
+        uint32_t mid = begin + n / 2;
+        bool use_median = false;
+        // depth guard: a subtree of n prims needs ceil(log2(n / leaf)) more levels if split evenly
+        const int levels_left = RT_BVH_MAX_DEPTH - depth;
+        if (double(n) > std::ldexp(double(RT_BVH_LEAF), std::max(0, levels_left - 1)) * 0.5) use_median = true;
+        int axis = 0;
+        float ext[3] = {cb.hi[0] - cb.lo[0], cb.hi[1] - cb.lo[1], cb.hi[2] - cb.lo[2]};
+        if (ext[1] > ext[axis]) axis = 1;
+        if (ext[2] > ext[axis]) axis = 2;
+        if (!(ext[axis] > 0.0f)) use_median = true;  // all centroids coincide
+        if (!use_median) {
+            float best_cost = INFINITY;
+            int best_axis = -1, best_bin = -1;
+            for (int ax = 0; ax < 3; ax++) {
+                if (!(ext[ax] > 0.0f)) continue;
+                Box bb[BINS];
+                uint32_t bc[BINS];
+                for (int k = 0; k < BINS; k++) bb[k].reset(), bc[k] = 0;
+                const float scale = float(BINS) / ext[ax];
+                for (uint32_t i = begin; i < end; i++) {
+                    int k = std::min(BINS - 1, std::max(0, int((centroid[3 * size_t(prims[i]) + ax] - cb.lo[ax]) * scale)));
+                    bb[k].grow(pbox[prims[i]]);
+                    bc[k]++;
+                }
+                float right_area[BINS];
+                uint32_t right_cnt[BINS];
+                Box acc;
+                acc.reset();
+                uint32_t cnt = 0;
+                for (int k = BINS - 1; k > 0; k--) {
+                    acc.grow(bb[k]);
+                    cnt += bc[k];
+                    right_area[k] = cnt ? acc.half_area() : 0.0f;
+                    right_cnt[k] = cnt;
+                }
+                acc.reset();
+                cnt = 0;
+                for (int k = 0; k < BINS - 1; k++) {
+                    acc.grow(bb[k]);
+                    cnt += bc[k];
+                    if (cnt == 0 || right_cnt[k + 1] == 0) continue;
+                    float cost = acc.half_area() * float(cnt) + right_area[k + 1] * float(right_cnt[k + 1]);
+                    if (cost < best_cost) best_cost = cost, best_axis = ax, best_bin = k;
+                }
+            }
+            if (best_axis < 0) {
+                use_median = true;
+            } else {
+                const float scale = float(BINS) / ext[best_axis];
+                const float lo = cb.lo[best_axis];
+                auto it = std::partition(prims.begin() + begin, prims.begin() + end, [&](uint32_t p) {
+                    int k = std::min(BINS - 1, std::max(0, int((centroid[3 * size_t(p) + best_axis] - lo) * scale)));
+                    return k <= best_bin;
+                });
+                mid = uint32_t(it - prims.begin());
+                if (mid == begin || mid == end) use_median = true;
+                else axis = best_axis;
+            }
+        }
+        if (use_median) {
+            mid = begin + n / 2;
+            std::nth_element(prims.begin() + begin, prims.begin() + mid, prims.begin() + end, [&](uint32_t a, uint32_t c) {
+                float ca = centroid[3 * size_t(a) + axis], cc = centroid[3 * size_t(c) + axis];
+                return ca < cc || (ca == cc && a < c);
+            });
+        }
+        build(begin, mid, depth + 1);  // left child is me + 1
+        uint32_t right = build(mid, end, depth + 1);
+        nodes[me].first = right;
+        nodes[me].count = uint32_t(axis) << RT_BVH_AXIS_SHIFT;
+        return me;
+    }
+};
+
+inline float next_down(float x) { return std::nextafter(x, -INFINITY); }
+inline float next_up(float x) { return std::nextafter(x, INFINITY); }
+
+}  // namespace
+
+void rt_build_bvh(const rthip_scene_desc *s, std::vector<DevBvhNode> &nodes, std::vector<uint32_t> &prims) {
     nodes.clear();
     prims.clear();
+    const size_t ns = s->n_spheres, nt = s->n_triangles, n = ns + nt;
+    if (n == 0) return;
+    Builder B(prims, nodes);
+    B.pbox.resize(n);
+    B.centroid.resize(3 * n);
+    for (size_t i = 0; i < ns; i++) {
+        const rthip_sphere &sp = s->spheres[i];
+        const float r = std::fabs(float(sp.radius));
+        Box &b = B.pbox[i];
+        for (int k = 0; k < 3; k++) {
+            const float c = float(sp.center[k]);
+            // pad by a few ulps: the float sphere test may accept points marginally outside the exact sphere
+            const float pad = 4e-6f * (std::fabs(c) + r) + 1e-30f;
+            b.lo[k] = next_down(c - r - pad), b.hi[k] = next_up(c + r + pad);
+            B.centroid[3 * i + k] = c;
+        }
+    }
+    for (size_t i = 0; i < nt; i++) {
+        const rthip_triangle &t = s->triangles[i];
+        Box &b = B.pbox[ns + i];
+        b.reset();
+        float v[3][3];
+        for (int k = 0; k < 3; k++) v[0][k] = float(t.v0[k]), v[1][k] = float(t.v1[k]), v[2][k] = float(t.v2[k]);
+        for (int j = 0; j < 3; j++) b.grow_pt(v[j]);
+        for (int k = 0; k < 3; k++) {
+            const float m = std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k]));
+            const float pad = 4e-6f * (m + (b.hi[k] - b.lo[k])) + 1e-30f;
+            B.centroid[3 * (ns + i) + k] = 0.5f * (b.lo[k] + b.hi[k]);
+            b.lo[k] = next_down(b.lo[k] - pad), b.hi[k] = next_up(b.hi[k] + pad);
+        }
+    }
+    prims.resize(n);
+    std::iota(prims.begin(), prims.end(), 0u);
+    nodes.reserve(2 * n / RT_BVH_LEAF + 16);
+    B.build(0, uint32_t(n), 0);
 }

@@ -38,8 +38,13 @@ struct DevTexInfo {
 
 struct DevLight { float px, py, pz, _p0, ir, ig, ib, _p1; };
 
-// Linear BVH node, 32 B. Leaf iff count > 0: prims [first, first+count) of the BVH-ordered
-// primitive index array; inner: left child = node index + 1 (depth-first layout), right child = `first`.
+// Linear BVH node, 32 B. Leaf iff (count & RT_BVH_COUNT_MASK) > 0: prims [first, first+count) of the
+// BVH-ordered primitive index array; inner: left child = node index + 1 (depth-first layout),
+// right child = `first`, split axis in the top two bits of `count` (near child first).
+#define RT_BVH_LEAF 4u
+#define RT_BVH_MAX_DEPTH 32
+#define RT_BVH_COUNT_MASK 0x3fffffffu
+#define RT_BVH_AXIS_SHIFT 30
 struct DevBvhNode {
     float lo[3];
     uint32_t first;
@@ -79,5 +84,8 @@ struct KernelParams {
     unsigned long long *stats;  // RT_STAT_* counters, RT_STAT_SHARDS shards of RT_STAT_N
 };
 
-enum { RT_STAT_PATHS = 0, RT_STAT_RAYS = 1, RT_STAT_SPHERE = 2, RT_STAT_PLANE = 3, RT_STAT_TRI = 4, RT_STAT_NODE = 5, RT_STAT_N = 8 };
+enum {
+    RT_STAT_PATHS = 0, RT_STAT_RAYS = 1, RT_STAT_SPHERE = 2, RT_STAT_PLANE = 3, RT_STAT_TRI = 4, RT_STAT_NODE = 5,
+    RT_STAT_HIT0 = 6 /* +kind, 4 slots */, RT_STAT_SKY = 10, RT_STAT_SHADOW = 11, RT_STAT_N = 12
+};
 #define RT_STAT_SHARDS 64

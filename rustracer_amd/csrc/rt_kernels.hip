@@ -92,36 +92,144 @@ __device__ __forceinline__ bool hit_tri(rt_f4 v0, rt_f4 e1_, rt_f4 e2_, f3 o, f3
         h.shape = (idx);                             \
         __VA_ARGS__;                                 \
     }
+// the same rule when shapes are NOT visited in index order (BVH): smaller t, or equal t and larger index
+#define RT_TAKE_ANY_ORDER(ok, tnew, idx, ...)                                                    \
+    if ((ok) && ((tnew) < h.t || ((tnew) == h.t && (h.shape == RT_NONE || (idx) > h.shape)))) { \
+        h.t = (tnew);                                                                            \
+        h.shape = (idx);                                                                         \
+        __VA_ARGS__;                                                                             \
+    }
 
-template <bool STATS>
-__device__ __forceinline__ HitRec closest_hit(const KernelParams &P, f3 o, f3 d, uint32_t self, uint32_t *cnt) {
+// ---- linear BVH traversal (extension; big scenes) --------------------------------------------
+// Per-lane stack in LDS ([level][thread]: conflict-free), near child first by the split axis.
+// A node is entered iff the ray's slab interval overlaps (T_MIN, min(best t, t_max)] — INCLUSIVE of
+// the current best t, so that an equal-t shape with a larger index is still found (ray.rs:55-61).
+#define RT_STACK_AT(level) s_stack[(level) * 256 + threadIdx.x]
+
+template <bool STATS, bool ANY>
+__device__ __forceinline__ bool bvh_traverse(const KernelParams &P, f3 o, f3 d, float a, float inv_a, float t_max, uint32_t self, HitRec &h,
+                                             uint32_t *cnt, uint32_t *s_stack) {
+    const f3 inv_d = mk3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+    const uint32_t tri_base = P.n_spheres + P.n_planes;
+    int sp = 0;
+    uint32_t node = 0;
+    for (;;) {
+        const rt_f4 n0 = ((const rt_f4 *)P.bvh_nodes)[2 * node], n1 = ((const rt_f4 *)P.bvh_nodes)[2 * node + 1];
+        if (STATS) cnt[RT_STAT_NODE]++;
+        const float ax = (n0.x - o.x) * inv_d.x, bx = (n1.x - o.x) * inv_d.x;
+        const float ay = (n0.y - o.y) * inv_d.y, by = (n1.y - o.y) * inv_d.y;
+        const float az = (n0.z - o.z) * inv_d.z, bz = (n1.z - o.z) * inv_d.z;
+        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
+        const float limit = ANY ? t_max : fminf(h.t, t_max);
+        if (tn <= tf && tn <= limit && tf >= RT_T_MIN) {
+            const uint32_t first = __float_as_uint(n0.w), cw = __float_as_uint(n1.w);
+            const uint32_t count = cw & RT_BVH_COUNT_MASK;
+            if (count) {
+                for (uint32_t k = 0; k < count; k++) {
+                    const uint32_t id = P.bvh_prims[first + k];
+                    if (id < P.n_bvh_spheres) {
+                        float t;
+                        bool ok = hit_sphere(P.sph_geom[id], o, d, a, inv_a, RT_T_MIN, t_max, id == self, t);
+                        if (STATS) cnt[RT_STAT_SPHERE]++;
+                        if (ANY) {
+                            if (ok) return true;
+                        } else {
+                            RT_TAKE_ANY_ORDER(ok, t, id, (void)0)
+                        }
+                    } else {
+                        const uint32_t ti = id - P.n_bvh_spheres;
+                        float t, b1, b2;
+                        bool ok = hit_tri(P.tri_geom[3 * ti], P.tri_geom[3 * ti + 1], P.tri_geom[3 * ti + 2], o, d, RT_T_MIN, t_max, t, b1, b2);
+                        if (STATS) cnt[RT_STAT_TRI]++;
+                        if (ANY) {
+                            if (ok) return true;
+                        } else {
+                            RT_TAKE_ANY_ORDER(ok, t, tri_base + ti, (h.b1 = b1, h.b2 = b2))
+                        }
+                    }
+                }
+            } else {
+                const uint32_t axis = cw >> RT_BVH_AXIS_SHIFT;
+                const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+                const uint32_t left = node + 1, right = first;
+                const bool right_first = da < 0.0f;
+                RT_STACK_AT(sp) = right_first ? left : right;
+                sp++;
+                node = right_first ? right : left;
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        node = RT_STACK_AT(sp);
+    }
+    return false;
+}
+
+template <bool STATS, bool BVH>
+__device__ __forceinline__ HitRec closest_hit(const KernelParams &P, f3 o, f3 d, uint32_t self, uint32_t *cnt, uint32_t *s_stack) {
     HitRec h;
     h.t = __builtin_inff();
     h.shape = RT_NONE;
     h.b1 = h.b2 = 0.0f;
     const float a = dot(d, d);
     const float inv_a = fast_rcp(a);
-    for (uint32_t i = 0; i < P.n_spheres; i++) {  // wave-uniform index: scalar loads
-        float t;
-        bool ok = hit_sphere(P.sph_geom[i], o, d, a, inv_a, RT_T_MIN, RT_T_MAX, i == self, t);
-        RT_TAKE(ok, t, i, (void)0)
+    if (!BVH) {
+        for (uint32_t i = 0; i < P.n_spheres; i++) {  // wave-uniform index: scalar loads
+            float t;
+            bool ok = hit_sphere(P.sph_geom[i], o, d, a, inv_a, RT_T_MIN, RT_T_MAX, i == self, t);
+            RT_TAKE(ok, t, i, (void)0)
+        }
     }
     for (uint32_t i = 0; i < P.n_planes; i++) {
         float t;
         bool ok = hit_plane(P.pln_geom[4 * i], o, d, RT_T_MIN, RT_T_MAX, t);
         RT_TAKE(ok, t, P.n_spheres + i, (void)0)
     }
-    for (uint32_t i = 0; i < P.n_tris; i++) {
-        float t, b1, b2;
-        bool ok = hit_tri(P.tri_geom[3 * i], P.tri_geom[3 * i + 1], P.tri_geom[3 * i + 2], o, d, RT_T_MIN, RT_T_MAX, t, b1, b2);
-        RT_TAKE(ok, t, P.n_spheres + P.n_planes + i, (h.b1 = b1, h.b2 = b2))
+    if (!BVH) {
+        for (uint32_t i = 0; i < P.n_tris; i++) {
+            float t, b1, b2;
+            bool ok = hit_tri(P.tri_geom[3 * i], P.tri_geom[3 * i + 1], P.tri_geom[3 * i + 2], o, d, RT_T_MIN, RT_T_MAX, t, b1, b2);
+            RT_TAKE(ok, t, P.n_spheres + P.n_planes + i, (h.b1 = b1, h.b2 = b2))
+        }
+        if (STATS) {
+            cnt[RT_STAT_SPHERE] += P.n_spheres;
+            cnt[RT_STAT_TRI] += P.n_tris;
+        }
+    } else {
+        bvh_traverse<STATS, false>(P, o, d, a, inv_a, RT_T_MAX, self, h, cnt, s_stack);
     }
-    if (STATS) {
-        cnt[RT_STAT_SPHERE] += P.n_spheres;
-        cnt[RT_STAT_PLANE] += P.n_planes;
-        cnt[RT_STAT_TRI] += P.n_tris;
-    }
+    if (STATS) cnt[RT_STAT_PLANE] += P.n_planes;
     return h;
+}
+
+// extension: shadow-ray any-hit for the point-light mode: direction = light - p, occluded iff some
+// shape is hit with T_MIN < t < 1.
+template <bool STATS, bool BVH>
+__device__ __forceinline__ bool occluded(const KernelParams &P, f3 o, f3 d, uint32_t self, uint32_t *cnt, uint32_t *s_stack) {
+    const float a = dot(d, d);
+    const float inv_a = fast_rcp(a);
+    bool occ = false;
+    float t, b1, b2;
+    if (!BVH) {
+        for (uint32_t i = 0; i < P.n_spheres; i++) occ |= hit_sphere(P.sph_geom[i], o, d, a, inv_a, RT_T_MIN, 1.0f, i == self, t);
+        for (uint32_t i = 0; i < P.n_tris; i++)
+            occ |= hit_tri(P.tri_geom[3 * i], P.tri_geom[3 * i + 1], P.tri_geom[3 * i + 2], o, d, RT_T_MIN, 1.0f, t, b1, b2);
+        if (STATS) {
+            cnt[RT_STAT_SPHERE] += P.n_spheres;
+            cnt[RT_STAT_TRI] += P.n_tris;
+        }
+    }
+    for (uint32_t i = 0; i < P.n_planes; i++) occ |= hit_plane(P.pln_geom[4 * i], o, d, RT_T_MIN, 1.0f, t);
+    if (STATS) cnt[RT_STAT_PLANE] += P.n_planes;
+    if (BVH && !occ) {
+        HitRec dummy;
+        dummy.t = 1.0f;
+        dummy.shape = RT_NONE;
+        occ = bvh_traverse<STATS, true>(P, o, d, a, inv_a, 1.0f, self, dummy, cnt, s_stack);
+    }
+    return occ;
 }
 
 // Ray::background_color — ray.rs:89-93
@@ -152,8 +260,10 @@ __device__ __forceinline__ uint32_t texture_wrap(float val, float scale, uint32_
 __device__ __forceinline__ float acos_f32(float x) { return acosf(x); }
 
 // One full pass over a pixel: generate_pixel (lib.rs:269-316) with project_ray (ray.rs:42-87) inlined.
-template <bool STATS>
+template <bool STATS, bool BVH, bool LIGHTS>
 __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
+    __shared__ uint32_t s_stack_mem[BVH ? RT_BVH_MAX_DEPTH * 256 : 1];
+    uint32_t *s_stack = s_stack_mem;
     const uint32_t tiles_x = (P.width + 15u) >> 4;
     const uint32_t tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -180,6 +290,7 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
         uint32_t key, bounce;
         uint32_t self = RT_NONE;  // shape the current ray starts on
         f3 o, d, T;
+        f3 Ld = mk3(0.0f, 0.0f, 0.0f);  // extension: direct light gathered along the path (point-light mode)
         auto new_path = [&]() {
             key = rt_path_key(pkey, P.sample0 + s);
             // lib.rs:282-285: x jitter first
@@ -190,6 +301,7 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
             T = mk3(1.0f, 1.0f, 1.0f);
             bounce = 0;
             self = RT_NONE;
+            if (LIGHTS) Ld = mk3(0.0f, 0.0f, 0.0f);
         };
         new_path();
         for (;;) {
@@ -198,12 +310,13 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
             HitRec h;
             h.shape = RT_NONE;
             if (bounce != P.max_depth) {  // ray.rs:70-72: depth exhausted -> sky without a scene query
-                h = closest_hit<STATS>(P, o, d, self, cnt);
+                h = closest_hit<STATS, BVH>(P, o, d, self, cnt, s_stack);
                 cnt[RT_STAT_RAYS]++;
             }
             if (h.shape == RT_NONE) {  // ray.rs:85
                 L = T * sky_color(d);
                 done = true;
+                if (STATS) cnt[RT_STAT_SKY]++;
             } else {
                 const f3 p = fma3(d, h.t, o);  // ray.rs:30-32
                 // ---- shape-specific: normal, material, texture coordinates (sphere.rs:63-73) ----
@@ -231,6 +344,10 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                 }
                 const DevMaterial m = P.materials[mat];
                 const uint32_t ctr = 2u + 2u * bounce;
+                if (STATS) {
+#pragma unroll
+                    for (uint32_t kk = 0; kk < 4; kk++) cnt[RT_STAT_HIT0 + kk] += (m.kind == kk) ? 1u : 0u;
+                }
                 if (m.kind == RTHIP_MAT_TEXTURE) {
                     // Texture::scatter — texture.rs:45-57; bounce -> None (texture.rs:59-61) => path ends, ray.rs:80
                     float U, V;
@@ -254,6 +371,32 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                     L = T * c;
                     done = true;
                 } else {
+                    if (LIGHTS && m.kind != RTHIP_MAT_DIELECTRIC) {
+                        // extension (RTHIP_F_POINT_LIGHTS): Lambert N.L on Lambertian, Phong (R.L)^s on Metal, one shadow ray per light
+                        f3 sum = mk3(0.0f, 0.0f, 0.0f);
+                        const f3 dhl = normalize(d);
+                        const f3 rl = fma3(n, -2.0f * dot(dhl, n), dhl);
+                        for (uint32_t li = 0; li < P.n_lights; li++) {
+                            const DevLight lt = P.lights[li];
+                            const f3 to_light = mk3(lt.px - p.x, lt.py - p.y, lt.pz - p.z);
+                            const float dist2 = dot(to_light, to_light);
+                            const f3 ldir = to_light * fast_rsq(dist2);
+                            float w;
+                            if (m.kind == RTHIP_MAT_LAMBERTIAN)
+                                w = fmaxf(0.0f, dot(n, ldir));
+                            else
+                                w = (m.shininess > 0.0f) ? __powf(fmaxf(0.0f, dot(rl, ldir)), m.shininess) : 0.0f;
+                            if (w > 0.0f) {
+                                cnt[RT_STAT_RAYS]++;
+                                if (STATS) cnt[RT_STAT_SHADOW]++;
+                                if (!occluded<STATS, BVH>(P, p, to_light, h.shape, cnt, s_stack)) {
+                                    const float s = w * fast_rcp(dist2);
+                                    sum = sum + mk3(m.ar * lt.ir, m.ag * lt.ig, m.ab * lt.ib) * s;
+                                }
+                            }
+                        }
+                        Ld = Ld + T * sum;
+                    }
                     T = T * mk3(m.tr, m.tg, m.tb);  // scatter: albedo/pi * 3 (lambertian_diffuse.rs:53-66, metal.rs:45-56, dielectric.rs:56-66)
                     f3 nd;
                     done = false;
@@ -296,6 +439,7 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                 }
             }
             if (done) {
+                if (LIGHTS) L = L + Ld;
                 acc = acc + L;  // lib.rs:287
                 cnt[RT_STAT_PATHS]++;
                 s++;
@@ -340,23 +484,37 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
 
 // Raytracer::get_shape — lib.rs:262-267: one un-jittered primary ray, index of the closest shape.
 __global__ void pick_kernel(const KernelParams P, float u, float v, long long *out) {
+    __shared__ uint32_t s_stack[RT_BVH_MAX_DEPTH * 256];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t cnt[RT_STAT_N];
     f3 o = mk3(P.ox, P.oy, P.oz);
     f3 d = mk3(fmaf(P.vx, v, fmaf(P.hx, u, P.d00x)), fmaf(P.vy, v, fmaf(P.hy, u, P.d00y)), fmaf(P.vz, v, fmaf(P.hz, u, P.d00z)));
-    HitRec h = closest_hit<false>(P, o, d, RT_NONE, cnt);
+    HitRec h = P.n_bvh_nodes ? closest_hit<false, true>(P, o, d, RT_NONE, cnt, s_stack) : closest_hit<false, false>(P, o, d, RT_NONE, cnt, s_stack);
     *out = (h.shape == RT_NONE) ? -1ll : (long long)h.shape;
 }
 
 // ---- launch wrappers (called from rthip_api.cpp) -----------------------------------------
+template <bool STATS, bool BVH>
+static void launch_variant(const KernelParams &P, bool lights, uint32_t blocks, hipStream_t stream) {
+    if (lights)
+        hipLaunchKernelGGL((render_kernel<STATS, BVH, true>), dim3(blocks), dim3(256), 0, stream, P);
+    else
+        hipLaunchKernelGGL((render_kernel<STATS, BVH, false>), dim3(blocks), dim3(256), 0, stream, P);
+}
+
 extern "C" hipError_t rt_launch_render(const KernelParams *P, int count_stats, hipStream_t stream) {
     const uint32_t tiles_x = (P->width + 15u) >> 4, tiles_y = (P->owned_rows + 15u) >> 4;
     const uint32_t blocks = tiles_x * tiles_y;
     if (blocks == 0) return hipSuccess;
-    if (count_stats)
-        hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(256), 0, stream, *P);
-    else
-        hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(256), 0, stream, *P);
+    const bool lights = (P->flags & RTHIP_F_POINT_LIGHTS) && P->n_lights > 0;
+    const bool bvh = P->n_bvh_nodes > 0;
+    if (count_stats) {
+        if (bvh) launch_variant<true, true>(*P, lights, blocks, stream);
+        else launch_variant<true, false>(*P, lights, blocks, stream);
+    } else {
+        if (bvh) launch_variant<false, true>(*P, lights, blocks, stream);
+        else launch_variant<false, false>(*P, lights, blocks, stream);
+    }
     return hipGetLastError();
 }
 

@@ -163,6 +163,17 @@ const char *rthip_status_string(int status) {
     }
 }
 
+double rthip_algorithmic_flops(const rthip_stats *s) {
+    if (!s) return 0.0;
+    const double hits = double(s->hits[0]) + double(s->hits[1]) + double(s->hits[2]) + double(s->hits[3]);
+    return RTHIP_FLOPS_RAY_SETUP * double(s->paths) + RTHIP_FLOPS_SEGMENT * double(s->rays) + RTHIP_FLOPS_SPHERE_TEST * double(s->sphere_tests) +
+           RTHIP_FLOPS_PLANE_TEST * double(s->plane_tests) + RTHIP_FLOPS_TRI_TEST * double(s->tri_tests) +
+           RTHIP_FLOPS_NODE_TEST * double(s->node_tests) + RTHIP_FLOPS_HIT * hits + RTHIP_FLOPS_SKY * double(s->sky_evals) +
+           RTHIP_FLOPS_LAMBERTIAN * double(s->hits[RTHIP_MAT_LAMBERTIAN]) + RTHIP_FLOPS_METAL * double(s->hits[RTHIP_MAT_METAL]) +
+           RTHIP_FLOPS_DIELECTRIC * double(s->hits[RTHIP_MAT_DIELECTRIC]) + RTHIP_FLOPS_TEXTURE * double(s->hits[RTHIP_MAT_TEXTURE]) +
+           RTHIP_FLOPS_TONEMAP * double(s->paths) / double(s->nb_samples ? s->nb_samples : 1);
+}
+
 const char *rthip_last_error(const rthip_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
 int rthip_device_count(int *out_count) {
@@ -486,6 +497,9 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rg
                 stats->plane_tests += h[sh * RT_STAT_N + RT_STAT_PLANE];
                 stats->tri_tests += h[sh * RT_STAT_N + RT_STAT_TRI];
                 stats->node_tests += h[sh * RT_STAT_N + RT_STAT_NODE];
+                for (int k = 0; k < 4; k++) stats->hits[k] += h[sh * RT_STAT_N + RT_STAT_HIT0 + k];
+                stats->sky_evals += h[sh * RT_STAT_N + RT_STAT_SKY];
+                stats->shadow_rays += h[sh * RT_STAT_N + RT_STAT_SHADOW];
             }
             stats->rows = rows;
             stats->nb_samples = ctx->nb_samples;
