@@ -63,10 +63,12 @@ def lib():
         l.oracle_reflect.restype = None
         l.oracle_path_key.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         l.oracle_path_key.restype = C.c_uint32
-        l.oracle_rng_u32.argtypes = [C.c_uint32, C.c_uint32]
-        l.oracle_rng_u32.restype = C.c_uint32
-        l.oracle_rng_unit.argtypes = [C.c_uint32, C.c_uint32]
-        l.oracle_rng_unit.restype = C.c_double
+        l.oracle_rng_first.argtypes = [C.c_uint32, C.c_uint32]
+        l.oracle_rng_first.restype = C.c_uint32
+        l.oracle_rng_second.argtypes = [C.c_uint32]
+        l.oracle_rng_second.restype = C.c_uint32
+        l.oracle_rng_pair.argtypes = [C.c_uint32, C.c_uint32, _P(C.c_double), _P(C.c_double)]
+        l.oracle_rng_pair.restype = None
         l.oracle_random_unit_vector.argtypes = [C.c_uint32, C.c_uint32, _P(C.c_double)]
         l.oracle_random_unit_vector.restype = None
         l.oracle_project_ray.argtypes = [_P(abi.SceneDesc), _P(C.c_double), _P(C.c_double), C.c_uint32, C.c_uint32, C.c_int, _P(C.c_double),

@@ -109,8 +109,9 @@ void oracle_reflect(const double ray[3], const double normal[3], double out[3]) 
 }
 
 uint32_t oracle_path_key(uint32_t seed, uint32_t pixel_index, uint32_t sample) { return path_key(seed, pixel_index, sample); }
-uint32_t oracle_rng_u32(uint32_t key, uint32_t counter) { return rng_u32(key, counter); }
-double oracle_rng_unit(uint32_t key, uint32_t counter) { return rng_unit<double>(key, counter); }
+uint32_t oracle_rng_first(uint32_t key, uint32_t slot) { return rng_first(key, slot); }
+uint32_t oracle_rng_second(uint32_t h) { return rng_second(h); }
+void oracle_rng_pair(uint32_t key, uint32_t slot, double *ua, double *ub) { rng_pair<double>(key, slot, ua, ub); }
 void oracle_random_unit_vector(uint32_t key, uint32_t counter, double out[3]) {
     V3<double> v = random_unit_vector<double>(key, counter);
     out[0] = v.x, out[1] = v.y, out[2] = v.z;
@@ -134,14 +135,18 @@ int oracle_trace_path(const rthip_scene_desc *scene, const rthip_camera *cam, co
     const uint32_t key = path_key(p->seed, y * p->width + x, sample);
     if (precision == 64) {
         Scene<double> s(*scene);
-        double ox = (double(x) + rng_unit<double>(key, 0)) / (double(p->width) - 1.0);
-        double oy = (double(y) + rng_unit<double>(key, 1)) / (double(p->height) - 1.0);
+        double jx, jy;
+        rng_pair<double>(key, 0, &jx, &jy);
+        double ox = (double(x) + jx) / (double(p->width) - 1.0);
+        double oy = (double(y) + jy) / (double(p->height) - 1.0);
         V3<double> c = project_ray<double>(s, emit_ray_at<double>(*cam, ox, oy), p->max_depth, key, false, nullptr);
         rgb[0] = c.x, rgb[1] = c.y, rgb[2] = c.z;
     } else {
         Scene<float> s(*scene);
-        float ox = (float(x) + rng_unit<float>(key, 0)) / (float(p->width) - 1.0f);
-        float oy = (float(y) + rng_unit<float>(key, 1)) / (float(p->height) - 1.0f);
+        float jx, jy;
+        rng_pair<float>(key, 0, &jx, &jy);
+        float ox = (float(x) + jx) / (float(p->width) - 1.0f);
+        float oy = (float(y) + jy) / (float(p->height) - 1.0f);
         V3<float> c = project_ray<float>(s, emit_ray_at<float>(*cam, ox, oy), p->max_depth, key, false, nullptr);
         rgb[0] = c.x, rgb[1] = c.y, rgb[2] = c.z;
     }

@@ -29,8 +29,13 @@ namespace oracle {
 
 // ----------------------------------------------------------------------------------------
 // Counter-based RNG (replaces rand 0.7 SmallRng + gen_range).
-// Stateless: value = f(seed, pixel_index, sample, bounce, dim). The device kernel implements
-// the same integer function independently (rustracer_amd/csrc/rt_rng.h).
+// Stateless: value = f(seed, pixel_index, sample, slot). The device kernel implements the same
+// integer function independently (rustracer_amd/csrc/rt_rng.h); spec in DESIGN.md §RNG.
+//   pixel_key = mix32(mix32(seed ^ 0x52545243) + pixel_index)
+//   pair of (sample s, slot j): h = mix32(pixel_key + (s*256 + j)*0x9E3779B9)
+//       u_a = (h >> 8) / 2^24;  g = h*0x2C1B3C6D; g ^= g >> 15;  u_b = (g >> 8) / 2^24
+//   slot 0: pixel jitter (u_a = x drawn first, u_b = y; lib.rs:283,285);
+//   slot 1+bounce: material draws of segment `bounce` (u_a drawn first).
 // ----------------------------------------------------------------------------------------
 static inline uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
@@ -40,15 +45,25 @@ static inline uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     return x;
 }
+static inline uint32_t pixel_key(uint32_t seed, uint32_t pixel_index) { return mix32(mix32(seed ^ 0x52545243U) + pixel_index); }
+// "key" of a path = the counter of its slot 0
 static inline uint32_t path_key(uint32_t seed, uint32_t pixel_index, uint32_t sample) {
-    return mix32(mix32(mix32(seed ^ 0x52545243U) + pixel_index) + sample * 0x9E3779B9U);
+    return pixel_key(seed, pixel_index) + (sample * 256U) * 0x9E3779B9U;
 }
-// counter: 0,1 = pixel jitter x,y (lib.rs:283,285); 2+2*bounce+dim = material draws of segment `bounce`.
-static inline uint32_t rng_u32(uint32_t key, uint32_t counter) { return mix32(key + counter * 0x9E3779B9U); }
+static inline uint32_t rng_first(uint32_t key, uint32_t slot) { return mix32(key + slot * 0x9E3779B9U); }
+static inline uint32_t rng_second(uint32_t h) {
+    uint32_t g = h * 0x2C1B3C6DU;
+    return g ^ (g >> 15);
+}
 // U[0,1) on a 24-bit grid: exactly representable in binary32 and binary64, so both modes see the same xi.
 template <class Real>
-static inline Real rng_unit(uint32_t key, uint32_t counter) {
-    return Real(rng_u32(key, counter) >> 8) * Real(1.0 / 16777216.0);
+static inline Real unit_from_bits(uint32_t bits) { return Real(bits >> 8) * Real(1.0 / 16777216.0); }
+// the pair (u_a, u_b) of a slot
+template <class Real>
+static inline void rng_pair(uint32_t key, uint32_t slot, Real *ua, Real *ub) {
+    const uint32_t h = rng_first(key, slot);
+    *ua = unit_from_bits<Real>(h);
+    *ub = unit_from_bits<Real>(rng_second(h));
 }
 
 // ----------------------------------------------------------------------------------------
@@ -375,9 +390,11 @@ struct Scene {
 // Lambertian/Metal::random_unit_vector — lambertian_diffuse.rs:39-45, metal.rs:31-37:
 // a = U[0,TAU) is drawn BEFORE z = U[-1,1).
 template <class Real>
-static inline V3<Real> random_unit_vector(uint32_t key, uint32_t counter) {
-    Real a = Consts<Real>::TAU * rng_unit<Real>(key, counter);
-    Real z = Real(-1.0) + Real(2.0) * rng_unit<Real>(key, counter + 1);
+static inline V3<Real> random_unit_vector(uint32_t key, uint32_t slot) {
+    Real ua, ub;
+    rng_pair<Real>(key, slot, &ua, &ub);
+    Real a = Consts<Real>::TAU * ua;
+    Real z = Real(-1.0) + Real(2.0) * ub;
     Real r = std::sqrt(Real(1.0) - z * z);
     return V3<Real>(r * std::cos(a), r * std::sin(a), z);
 }
@@ -447,7 +464,7 @@ static V3<Real> project_ray(const Scene<Real> &scene, Ray<Real> ray, uint32_t ma
         }
         const auto &m = scene.materials[scene.material_of(hit.shape)];
         if (st) st->hits[m.kind]++;
-        const uint32_t ctr = 2 + 2 * bounce;
+        const uint32_t ctr = 1 + bounce;  // RNG slot of this segment
         const Vec normal = scene.normal_at(hit);  // collision.rs:29-31
         const Real light_intensity = Real(3.0);   // "global lightning, to be changed"
         switch (m.kind) {
@@ -497,7 +514,7 @@ static V3<Real> project_ray(const Scene<Real> &scene, Ray<Real> ray, uint32_t ma
                 Vec refracted;
                 bool has_refracted = refract(ray.direction, outward_normal, refraction_index, &refracted);
                 Real reflect_prob = has_refracted ? schlick(cosine, m.param) : Real(1.0);  // always the material's ior: dielectric.rs:89
-                Real xi = rng_unit<Real>(key, ctr);                                         // drawn always: dielectric.rs:94
+                Real xi = unit_from_bits<Real>(rng_first(key, ctr));                        // drawn always: dielectric.rs:94
                 ray = Ray<Real>{hit.position, reflect_prob > xi ? reflected : refracted};
                 break;
             }
@@ -576,8 +593,10 @@ static void render(const rthip_scene_desc &desc, const rthip_camera &cam, const 
                 for (uint32_t s = 0; s < p.spp; s++) {
                     const uint32_t key = path_key(p.seed, pixel_index, sample0 + s);
                     // lib.rs:282-285: x jitter first, divisors are (width - 1), (height - 1)
-                    Real ox = (Real(x) + rng_unit<Real>(key, 0)) / (Real(p.width) - Real(1.0));
-                    Real oy = (Real(y) + rng_unit<Real>(key, 1)) / (Real(p.height) - Real(1.0));
+                    Real jx, jy;
+                    rng_pair<Real>(key, 0, &jx, &jy);
+                    Real ox = (Real(x) + jx) / (Real(p.width) - Real(1.0));
+                    Real oy = (Real(y) + jy) / (Real(p.height) - Real(1.0));
                     Ray<Real> r = emit_ray_at<Real>(cam, ox, oy);
                     samples_color = samples_color + project_ray(scene, r, p.max_depth, key, lights, &st);  // lib.rs:287
                     st.paths++;

@@ -241,9 +241,9 @@ __device__ __forceinline__ f3 sky_color(f3 d) {
 
 // Lambertian/Metal::random_unit_vector — lambertian_diffuse.rs:39-45, metal.rs:31-37 (a first, then z).
 // v_sin_f32 / v_cos_f32 take their argument in revolutions, so a = TAU*xi needs no multiply.
-__device__ __forceinline__ f3 random_unit_vector(uint32_t key, uint32_t ctr) {
-    float xa = rt_rng_unit(key, ctr);
-    float z = fmaf(2.0f, rt_rng_unit(key, ctr + 1), -1.0f);
+__device__ __forceinline__ f3 random_unit_vector(uint32_t h) {
+    float xa = rt_unit(h);
+    float z = fmaf(2.0f, rt_unit(rt_second(h)), -1.0f);
     float r = fast_sqrt(fmaf(-z, z, 1.0f));
     return mk3(r * __builtin_amdgcn_cosf(xa), r * __builtin_amdgcn_sinf(xa), z);
 }
@@ -292,10 +292,11 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
         f3 o, d, T;
         f3 Ld = mk3(0.0f, 0.0f, 0.0f);  // extension: direct light gathered along the path (point-light mode)
         auto new_path = [&]() {
-            key = rt_path_key(pkey, P.sample0 + s);
+            key = rt_counter(pkey, P.sample0 + s, 0);  // RNG counter of this path's slot 0
             // lib.rs:282-285: x jitter first
-            float u = (float(x) + rt_rng_unit(key, 0)) * P.inv_wm1;
-            float v = (float(y) + rt_rng_unit(key, 1)) * P.inv_hm1;
+            const uint32_t hj = rt_mix32(key);
+            float u = (float(x) + rt_unit(hj)) * P.inv_wm1;
+            float v = (float(y) + rt_unit(rt_second(hj))) * P.inv_hm1;
             o = cam_o;  // camera.rs:43-50
             d = mk3(fmaf(P.vx, v, fmaf(P.hx, u, P.d00x)), fmaf(P.vy, v, fmaf(P.hy, u, P.d00y)), fmaf(P.vz, v, fmaf(P.hz, u, P.d00z)));
             T = mk3(1.0f, 1.0f, 1.0f);
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                     mat = __float_as_uint(P.tri_geom[3 * i].w);
                 }
                 const DevMaterial m = P.materials[mat];
-                const uint32_t ctr = 2u + 2u * bounce;
+                const uint32_t hb = rt_mix32(key + (1u + bounce) * RT_RNG_GOLDEN);  // RNG slot 1 + bounce
                 if (STATS) {
 #pragma unroll
                     for (uint32_t kk = 0; kk < 4; kk++) cnt[RT_STAT_HIT0 + kk] += (m.kind == kk) ? 1u : 0u;
@@ -401,12 +402,12 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                     f3 nd;
                     done = false;
                     if (m.kind == RTHIP_MAT_LAMBERTIAN) {
-                        nd = n + random_unit_vector(key, ctr);  // lambertian_diffuse.rs:68-73
+                        nd = n + random_unit_vector(hb);  // lambertian_diffuse.rs:68-73
                     } else {
                         const f3 dh = normalize(d);
                         const f3 refl = fma3(n, -2.0f * dot(dh, n), dh);  // metal.rs:27-29, dielectric.rs:28-30
                         if (m.kind == RTHIP_MAT_METAL) {
-                            nd = fma3(random_unit_vector(key, ctr), m.param, refl);  // metal.rs:59-60
+                            nd = fma3(random_unit_vector(hb), m.param, refl);  // metal.rs:59-60
                             if (dot(nd, n) < 0.0f) {                                   // metal.rs:62-64 -> None -> ray.rs:80
                                 L = T;
                                 done = true;
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                             const float om = 1.0f - cosine;
                             const float om2 = om * om;
                             const float prob = (k < 0.0f) ? 1.0f : fmaf(1.0f - m.r1, om2 * om2 * om, m.r1);  // dielectric.rs:47-52,87-92
-                            const float xi = rt_rng_unit(key, ctr);                                              // dielectric.rs:94
+                            const float xi = rt_unit(hb);                                             // dielectric.rs:94
                             if (prob > xi) {
                                 nd = refl;
                             } else {

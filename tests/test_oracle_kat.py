@@ -134,35 +134,51 @@ def test_reflect_refract(oracle_mod):
     assert lib.oracle_refract((C.c_double * 3)(1, -0.1, 0), (C.c_double * 3)(0, 1, 0), 1.5, out) == 0
 
 
+def _mix32(x):
+    x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF; x ^= x >> 16
+    return x
+
+
 def test_rng_is_a_pure_function(oracle_mod):
+    """pins the RNG spec of DESIGN.md (shared with rustracer_amd/csrc/rt_rng.h) with plain-Python integers"""
     lib = oracle_mod.lib()
     k = lib.oracle_path_key(1, 12345, 7)
     assert k == lib.oracle_path_key(1, 12345, 7)
     assert k != lib.oracle_path_key(2, 12345, 7) and k != lib.oracle_path_key(1, 12346, 7) and k != lib.oracle_path_key(1, 12345, 8)
-    u = [lib.oracle_rng_unit(k, c) for c in range(64)]
-    assert all(0.0 <= x < 1.0 for x in u) and len(set(u)) == 64
-    assert all(x * 16777216.0 == int(x * 16777216.0) for x in u)  # 24-bit grid: exact in f32 and f64
-    # reference integers of the mixer (pins the spec shared with rustracer_amd/csrc/rt_rng.h)
-    def mix32(x):
-        x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF; x ^= x >> 16
-        return x
-    key = mix32((mix32((mix32(1 ^ 0x52545243) + 12345) & 0xFFFFFFFF) + 7 * 0x9E3779B9) & 0xFFFFFFFF)
-    assert k == key
-    assert lib.oracle_rng_u32(k, 5) == mix32((k + 5 * 0x9E3779B9) & 0xFFFFFFFF)
-    # uniformity smoke: mean of 2^16 draws
-    xs = np.array([lib.oracle_rng_unit(lib.oracle_path_key(9, i, 0), 0) for i in range(1 << 14)])
-    assert abs(xs.mean() - 0.5) < 0.01 and abs(xs.var() - 1 / 12) < 0.005
+    pixel_key = _mix32((_mix32(1 ^ 0x52545243) + 12345) & 0xFFFFFFFF)
+    assert k == (pixel_key + (7 * 256) * 0x9E3779B9) & 0xFFFFFFFF
+    for slot in (0, 1, 5, 51):
+        h = _mix32((k + slot * 0x9E3779B9) & 0xFFFFFFFF)
+        assert lib.oracle_rng_first(k, slot) == h
+        g = (h * 0x2C1B3C6D) & 0xFFFFFFFF
+        g ^= g >> 15
+        assert lib.oracle_rng_second(h) == g
+        ua, ub = C.c_double(), C.c_double()
+        lib.oracle_rng_pair(k, slot, C.byref(ua), C.byref(ub))
+        assert ua.value == (h >> 8) / 2.0 ** 24 and ub.value == (g >> 8) / 2.0 ** 24  # 24-bit grid: exact in f32 and f64
+        assert 0.0 <= ua.value < 1.0 and 0.0 <= ub.value < 1.0
+    # uniformity / independence smoke over pixels
+    ua, ub = C.c_double(), C.c_double()
+    xs = []
+    for i in range(1 << 13):
+        lib.oracle_rng_pair(lib.oracle_path_key(9, i, 0), 0, C.byref(ua), C.byref(ub))
+        xs.append((ua.value, ub.value))
+    xs = np.array(xs)
+    assert np.all(np.abs(xs.mean(0) - 0.5) < 0.012) and np.all(np.abs(xs.var(0) - 1 / 12) < 0.005)
+    assert abs(np.corrcoef(xs[:, 0], xs[:, 1])[0, 1]) < 0.04
 
 
 def test_random_unit_vector(oracle_mod):
     lib = oracle_mod.lib()
     out = (C.c_double * 3)()
-    for c in range(0, 40, 2):
-        lib.oracle_random_unit_vector(777, c, out)
+    ua, ub = C.c_double(), C.c_double()
+    for slot in range(1, 21):
+        lib.oracle_random_unit_vector(777, slot, out)
         v = np.array(out)
         assert abs(np.linalg.norm(v) - 1.0) < 1e-12
-        a = 2 * math.pi * lib.oracle_rng_unit(777, c)      # a drawn FIRST (lambertian_diffuse.rs:40)
-        z = -1 + 2 * lib.oracle_rng_unit(777, c + 1)
+        lib.oracle_rng_pair(777, slot, C.byref(ua), C.byref(ub))
+        a = 2 * math.pi * ua.value      # a drawn FIRST (lambertian_diffuse.rs:40)
+        z = -1 + 2 * ub.value
         assert close(v, (math.sqrt(1 - z * z) * math.cos(a), math.sqrt(1 - z * z) * math.sin(a), z), 1e-10)
 
 

@@ -1,0 +1,33 @@
+"""A/B timing of librthip variants on the bench workload: python tools/ab_bench.py libA.so libB.so ..."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from rustracer_amd import abi, flatten, presets, make_params
+from rustracer_amd.scene import Camera
+
+def load(path):
+    l = C.CDLL(path)
+    for name, (res, args) in abi.SYMBOLS.items():
+        fn = getattr(l, name); fn.restype = res; fn.argtypes = args
+    return l
+
+flat = flatten(presets.standalone_scene())
+libs = [(p, load(p)) for p in sys.argv[1:]]
+W, H = 3840, 2160
+spp = int(os.environ.get("SPP", "64")); depth = int(os.environ.get("DEPTH", "5"))
+ctxs = []
+for name, l in libs:
+    ctx = C.c_void_p(); assert l.rthip_create(0, C.byref(ctx)) == 0
+    assert l.rthip_upload_scene(ctx, C.byref(flat.desc)) == 0
+    cam = abi.Camera(); l.rthip_camera_lookat(-1.8, 1.0, 2.0, (C.c_double*3)(0,0,-1), C.byref(cam)); l.rthip_set_camera(ctx, C.byref(cam))
+    ctxs.append(ctx)
+out = np.zeros((H, W, 4), np.uint8)
+ref = None
+for rnd in range(4):
+    for (name, l), ctx in zip(libs, ctxs):
+        p = make_params(W, H, spp, depth, rnd)
+        st = abi.Stats()
+        rc = l.rthip_render(ctx, C.byref(p), out.ctypes.data, None, C.byref(st))
+        assert rc == 0, l.rthip_last_error(ctx)
+        crc = int(out.view(np.uint32).sum(dtype=np.uint64))
+        print(f"round {rnd} {os.path.basename(name):28s} kernel_ms={st.kernel_ms:8.3f} rays={st.rays} -> {st.rays/st.kernel_ms/1e3:9.1f} Mrays/s checksum={crc}")

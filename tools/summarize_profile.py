@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 CSVs written by tools/profile_bench.sh into profiles/<tag>_summary.md and
+profiles/traffic.json (HBM bytes per launch of the render kernel; FETCH_SIZE doubled per the gfx950
+correction of MI355X_MICROARCH.md §HBM — the render kernel's reads are 16-B-per-lane or scalar)."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+lines = [f"# rocprofv3 summary {tag} (python3 bench.py --steps 5 --warmup 1, 1 x MI355X)\n"]
+
+def find(pattern):
+    r = glob.glob(os.path.join(src, pattern), recursive=True)
+    return r[0] if r else None
+
+st = find("trace/**/*kernel_stats.csv")
+if st:
+    lines.append("## kernel stats (--kernel-trace --stats)\n")
+    lines.append("| kernel | calls | total ns | avg ns | % |\n|---|---|---|---|---|")
+    for row in csv.DictReader(open(st)):
+        lines.append(f"| {row['Name'][:70]} | {row['Calls']} | {row['TotalDurationNs']} | {float(row['AverageNs']):.0f} | {row['Percentage']} |")
+    lines.append("")
+kt = find("trace/**/*kernel_trace.csv")
+render_ns = []
+if kt:
+    for row in csv.DictReader(open(kt)):
+        if "render_kernel" in row["Kernel_Name"]:
+            render_ns.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            meta = (row.get("VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), row.get("Grid_Size"), row.get("Workgroup_Size"))
+    if render_ns:
+        lines.append(f"render_kernel dispatches: {len(render_ns)}, avg {sum(render_ns)/len(render_ns)/1e6:.3f} ms; VGPR/SGPR/LDS/grid/wg = {meta}\n")
+counters = defaultdict(list)
+for d in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
+    f = find(f"{d}/**/*counter_collection.csv")
+    if not f:
+        continue
+    for row in csv.DictReader(open(f)):
+        if "render_kernel" in row["Kernel_Name"]:
+            counters[row["Counter_Name"]].append(float(row["Counter_Value"]))
+if counters:
+    lines.append("## PMC, per render_kernel dispatch (mean over dispatches)\n")
+    lines.append("| counter | value |\n|---|---|")
+    mean = {k: sum(v) / len(v) for k, v in counters.items()}
+    for k in sorted(mean):
+        lines.append(f"| {k} | {mean[k]:.4g} |")
+    lines.append("")
+    if "SQ_INSTS_VALU" in mean and "SQ_WAVES" in mean:
+        lines.append(f"VALU instructions per wave: {mean['SQ_INSTS_VALU']/mean['SQ_WAVES']:.0f}")
+    if "SQ_ACTIVE_INST_VALU" in mean and "SQ_BUSY_CYCLES" in mean:
+        lines.append(f"SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES = {mean['SQ_ACTIVE_INST_VALU']/mean['SQ_BUSY_CYCLES']:.3f}")
+    if "SQ_THREAD_CYCLES_VALU" in mean and "SQ_ACTIVE_INST_VALU" in mean:
+        lines.append(f"VALU lane utilisation (THREAD_CYCLES_VALU / (ACTIVE_INST_VALU*64)) = {mean['SQ_THREAD_CYCLES_VALU']/(mean['SQ_ACTIVE_INST_VALU']*64):.3f}")
+    if "FETCH_SIZE" in mean or "WRITE_SIZE" in mean:
+        fetch_b = mean.get("FETCH_SIZE", 0.0) * 1024 * 2  # KiB -> B, x2 gfx950 correction
+        write_b = mean.get("WRITE_SIZE", 0.0) * 1024
+        lines.append(f"HBM traffic per launch: fetch {fetch_b/1e6:.2f} MB (FETCH_SIZE x2), write {write_b/1e6:.2f} MB")
+        with open(os.path.join(root, "profiles", "traffic.json"), "w") as f:
+            json.dump({"tag": tag, "spp": 256, "hbm_bytes_per_launch": fetch_b + write_b, "fetch_bytes": fetch_b, "write_bytes": write_b,
+                       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled (gfx950), mean over render_kernel dispatches"}, f)
+    if "GRBM_GUI_ACTIVE" in mean and render_ns:
+        lines.append(f"effective clock ~ GRBM_GUI_ACTIVE/8/time = {mean['GRBM_GUI_ACTIVE']/8/(sum(render_ns)/len(render_ns))*1e3:.0f} MHz")
+os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+out = os.path.join(root, "profiles", f"{tag}_summary.md")
+open(out, "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
