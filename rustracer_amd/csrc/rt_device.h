@@ -3,7 +3,9 @@
 //
 // HBM layout (all arrays 16-byte aligned, read-only during a render):
 //   sph_geom  [n_spheres] float4 {cx, cy, cz, r*r}          -> the closest-hit scan reads ONLY this
-//   sph_shade [n_spheres] float4 {1/r, mat_index(bits), 0, 0} -> read once per hit by the hitting lane
+//   sph_shade [n_spheres] 3 x float4 {c, 1/r} {albedo/pi*3, param} {kind, r1, 1/ior, material}: the merged
+//             sphere+material shading record, read once per hit by the hitting lane
+//   (scenes of <= RT_LDS_SPHERES spheres: both arrays are staged in LDS once per workgroup)
 //   pln_geom  [n_planes]  2 x float4 {nx,ny,nz, n.p0} {mat(bits), 0,0,0} + tangent frame 2 x float4
 //   tri_geom  [n_tris]    3 x float4 {v0, e1, e2} w = mat(bits)/0/0
 //   materials [n_mat]     3 x float4, see DevMaterial
@@ -13,6 +15,7 @@
 #pragma once
 #include <stdint.h>
 
+#define RT_LDS_SPHERES 256u
 #define RT_T_MIN 0.001f      /* raytracer_core/src/shapes/ray.rs:5 */
 #define RT_T_MAX 100000.0f   /* raytracer_core/src/shapes/ray.rs:6 */
 

@@ -6,8 +6,18 @@
 // (ray, throughput, bounce count) in VGPRs, and the `samples` loop of generate_pixel
 // (lib.rs:281-288) is folded into the same loop by path regeneration: a lane whose path ended
 // starts its pixel's next sample at once, so a wave only idles lanes at the very end of a tile.
-// Scene data indexed by a wave-uniform loop counter (the brute-force closest-hit scan of
-// ray.rs:47-67) is fetched through the scalar cache into SGPRs, i.e. it costs no VALU/LDS work.
+//
+// The kernel is VALU-issue bound (profiles/): what matters is the instruction count per segment
+// and the instruction class (measured on MI355X, tools/ubench/valu_rates.hip: VGPR-only VOP2
+// ~2.6-2.9 cycles per wave instruction, anything with an SGPR operand / VOP3-only / compare ~4.4,
+// transcendental ~8.5). Hence:
+//   * small scenes (MODE_LDS): sphere geometry and a merged per-sphere shading record are staged in
+//     LDS once per workgroup and read back with wave-uniform (broadcast) ds_read_b128, so the
+//     closest-hit scan of ray.rs:47-67 runs on VGPR operands;
+//   * the ray direction is kept NORMALISED with its length on the side (the reference's t is in
+//     units of the un-normalised direction: the window (T_MIN, T_MAX) is scaled by |d| instead);
+//     this removes a = d.d, the 1/a multiplies and every later normalize();
+//   * Lambertian and Metal share one random unit vector / one RNG hash per bounce.
 // No MFMA: there is no dense contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 
@@ -16,6 +26,8 @@
 #include "rt_rng.h"
 
 #define RT_NONE 0xffffffffu
+
+enum { MODE_LDS = 0, MODE_BVH = 1, MODE_GLOBAL = 2 };
 
 struct f3 {
     float x, y, z;
@@ -34,54 +46,71 @@ __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsq
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ f3 normalize(f3 a) { return a * fast_rsq(dot(a, a)); }
 
+// A ray with a UNIT direction; the reference's ray has an un-normalised direction of length `len`
+// and measures t in units of it, so t_reference = t / len and the reference's fixed window
+// T_MIN < t_ref < T_MAX (ray.rs:5-6) is tmin = T_MIN*len < t < tmax = T_MAX*len here.
+struct Ray {
+    f3 o, d;
+    float tmin, tmax;
+};
+
 struct HitRec {
-    float t;
+    float t;         // along the UNIT direction
     uint32_t shape;  // global shape index (spheres, then planes, then triangles); RT_NONE = miss
     float b1, b2;    // triangle barycentrics
 };
 
 // ---- primitive tests -------------------------------------------------------------------
-// Sphere::collide — sphere.rs:29-61. g = {cx, cy, cz, r*r}; a = d.d, inv_a = 1/a are per-segment.
+// Sphere::collide — sphere.rs:29-61 with a = 1. g = {cx, cy, cz, r*r}.
 // `on_surface`: the ray starts ON this sphere (it is the shape the path just bounced off). In the
-// reference's f64, c = |oc|^2 - r^2 is then ~1e-13, i.e. the roots are 0 and -2*half_b/a. In FP32
+// reference's f64, c = |oc|^2 - r^2 is then ~1e-13, i.e. the roots are 0 and -2*half_b. In FP32
 // the same c carries ~1e-3 of cancellation error on the radius-100 ground sphere (|oc|^2 ~ 1e4),
 // which turns ~0.1 % of grazing bounces into spurious self-hits beyond T_MIN; c is therefore set
 // to its exact value 0 for that one sphere ("FP32 robustness").
-__device__ __forceinline__ bool hit_sphere(rt_f4 g, f3 o, f3 d, float a, float inv_a, float t_min, float t_max, bool on_surface, float &t_out) {
-    f3 oc = mk3(o.x - g.x, o.y - g.y, o.z - g.z);
-    float half_b = dot(oc, d);
-    float c = on_surface ? 0.0f : dot(oc, oc) - g.w;
-    float disc = fmaf(half_b, half_b, -(a * c));
-    float root = fast_sqrt(disc);  // NaN when disc < 0: every comparison below is then false
-    float t0 = (-half_b - root) * inv_a;
-    float t1 = (root - half_b) * inv_a;
-    bool ok0 = t0 < t_max && t0 > t_min;
-    bool ok1 = t1 < t_max && t1 > t_min;
-    t_out = ok0 ? t0 : t1;
-    return disc > 0.0f && (ok0 || ok1);
+// Returns the NEGATED roots n0 = -t0 = half_b + root, n1 = -t1 = half_b - root (plain add/sub, no
+// source modifiers: those force the slower VOP3 encoding).
+__device__ __forceinline__ void sphere_roots(rt_f4 g, const Ray &r, bool on_surface, float &n0, float &n1) {
+    const f3 oc = mk3(r.o.x - g.x, r.o.y - g.y, r.o.z - g.z);
+    const float half_b = dot(oc, r.d);
+    float c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -g.w)));
+    c = on_surface ? 0.0f : c;
+    const float disc = fmaf(half_b, half_b, -c);
+    const float root = fast_sqrt(disc);  // NaN when disc < 0: every comparison on n0/n1 is then false
+    n0 = half_b + root;
+    n1 = half_b - root;
+}
+// The first root if it is inside the window, else the second (sphere.rs:38-58). t1 >= t0, hence
+// "the chosen root is > tmin" <=> t1 > tmin, and when t0 fails only because t0 >= tmax, t1 fails too.
+// A tangent ray (discriminant == 0 exactly, a miss in sphere.rs:36) is not told apart from a
+// grazing hit: in FP32 the sign of a zero discriminant is rounding noise either way.
+__device__ __forceinline__ bool hit_sphere(rt_f4 g, const Ray &r, bool on_surface, float &t_out) {
+    float n0, n1;
+    sphere_roots(g, r, on_surface, n0, n1);
+    const float t = (n0 < -r.tmin) ? -n0 : -n1;
+    t_out = t;
+    return (n1 < -r.tmin) & (t < r.tmax);
 }
 // extension: plane. g0 = {nx, ny, nz, n.p0}
-__device__ __forceinline__ bool hit_plane(rt_f4 g0, f3 o, f3 d, float t_min, float t_max, float &t_out) {
-    f3 n = mk3(g0.x, g0.y, g0.z);
-    float denom = dot(d, n);
-    float t = (g0.w - dot(o, n)) * fast_rcp(denom);
+__device__ __forceinline__ bool hit_plane(rt_f4 g0, const Ray &r, float &t_out) {
+    const f3 n = mk3(g0.x, g0.y, g0.z);
+    const float denom = dot(r.d, n);
+    const float t = (g0.w - dot(r.o, n)) * fast_rcp(denom);
     t_out = t;
-    return denom != 0.0f && t < t_max && t > t_min;
+    return denom != 0.0f && t < r.tmax && t > r.tmin;
 }
 // extension: Moller-Trumbore, two-sided. v0, e1 = v1-v0, e2 = v2-v0
-__device__ __forceinline__ bool hit_tri(rt_f4 v0, rt_f4 e1_, rt_f4 e2_, f3 o, f3 d, float t_min, float t_max, float &t_out, float &b1_out,
-                                        float &b2_out) {
-    f3 e1 = mk3(e1_.x, e1_.y, e1_.z), e2 = mk3(e2_.x, e2_.y, e2_.z);
-    f3 pvec = cross(d, e2);
-    float det = dot(e1, pvec);
-    float inv = fast_rcp(det);
-    f3 tvec = mk3(o.x - v0.x, o.y - v0.y, o.z - v0.z);
-    float b1 = dot(tvec, pvec) * inv;
-    f3 qvec = cross(tvec, e1);
-    float b2 = dot(d, qvec) * inv;
-    float t = dot(e2, qvec) * inv;
+__device__ __forceinline__ bool hit_tri(rt_f4 v0, rt_f4 e1_, rt_f4 e2_, const Ray &r, float &t_out, float &b1_out, float &b2_out) {
+    const f3 e1 = mk3(e1_.x, e1_.y, e1_.z), e2 = mk3(e2_.x, e2_.y, e2_.z);
+    const f3 pvec = cross(r.d, e2);
+    const float det = dot(e1, pvec);
+    const float inv = fast_rcp(det);
+    const f3 tvec = mk3(r.o.x - v0.x, r.o.y - v0.y, r.o.z - v0.z);
+    const float b1 = dot(tvec, pvec) * inv;
+    const f3 qvec = cross(tvec, e1);
+    const float b2 = dot(r.d, qvec) * inv;
+    const float t = dot(e2, qvec) * inv;
     t_out = t, b1_out = b1, b2_out = b2;
-    return det != 0.0f && b1 >= 0.0f && b1 <= 1.0f && b2 >= 0.0f && (b1 + b2) <= 1.0f && t < t_max && t > t_min;
+    return det != 0.0f && b1 >= 0.0f && b1 <= 1.0f && b2 >= 0.0f && (b1 + b2) <= 1.0f && t < r.tmax && t > r.tmin;
 }
 
 // Ray::find_collision — ray.rs:47-67: every shape against the FIXED window, keep the old hit only
@@ -102,27 +131,26 @@ __device__ __forceinline__ bool hit_tri(rt_f4 v0, rt_f4 e1_, rt_f4 e2_, f3 o, f3
 
 // ---- linear BVH traversal (extension; big scenes) --------------------------------------------
 // Per-lane stack in LDS ([level][thread]: conflict-free), near child first by the split axis.
-// A node is entered iff the ray's slab interval overlaps (T_MIN, min(best t, t_max)] — INCLUSIVE of
+// A node is entered iff the ray's slab interval overlaps (tmin, min(best t, tmax)] — INCLUSIVE of
 // the current best t, so that an equal-t shape with a larger index is still found (ray.rs:55-61).
 #define RT_STACK_AT(level) s_stack[(level) * 256 + threadIdx.x]
 
 template <bool STATS, bool ANY>
-__device__ __forceinline__ bool bvh_traverse(const KernelParams &P, f3 o, f3 d, float a, float inv_a, float t_max, uint32_t self, HitRec &h,
-                                             uint32_t *cnt, uint32_t *s_stack) {
-    const f3 inv_d = mk3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
+__device__ __forceinline__ bool bvh_traverse(const KernelParams &P, const Ray &r, uint32_t self, HitRec &h, uint32_t *cnt, uint32_t *s_stack) {
+    const f3 inv_d = mk3(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
     const uint32_t tri_base = P.n_spheres + P.n_planes;
     int sp = 0;
     uint32_t node = 0;
     for (;;) {
         const rt_f4 n0 = ((const rt_f4 *)P.bvh_nodes)[2 * node], n1 = ((const rt_f4 *)P.bvh_nodes)[2 * node + 1];
         if (STATS) cnt[RT_STAT_NODE]++;
-        const float ax = (n0.x - o.x) * inv_d.x, bx = (n1.x - o.x) * inv_d.x;
-        const float ay = (n0.y - o.y) * inv_d.y, by = (n1.y - o.y) * inv_d.y;
-        const float az = (n0.z - o.z) * inv_d.z, bz = (n1.z - o.z) * inv_d.z;
+        const float ax = (n0.x - r.o.x) * inv_d.x, bx = (n1.x - r.o.x) * inv_d.x;
+        const float ay = (n0.y - r.o.y) * inv_d.y, by = (n1.y - r.o.y) * inv_d.y;
+        const float az = (n0.z - r.o.z) * inv_d.z, bz = (n1.z - r.o.z) * inv_d.z;
         const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
         const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
-        const float limit = ANY ? t_max : fminf(h.t, t_max);
-        if (tn <= tf && tn <= limit && tf >= RT_T_MIN) {
+        const float limit = ANY ? r.tmax : fminf(h.t, r.tmax);
+        if (tn <= tf && tn <= limit && tf >= r.tmin) {
             const uint32_t first = __float_as_uint(n0.w), cw = __float_as_uint(n1.w);
             const uint32_t count = cw & RT_BVH_COUNT_MASK;
             if (count) {
@@ -130,7 +158,7 @@ __device__ __forceinline__ bool bvh_traverse(const KernelParams &P, f3 o, f3 d, 
                     const uint32_t id = P.bvh_prims[first + k];
                     if (id < P.n_bvh_spheres) {
                         float t;
-                        bool ok = hit_sphere(P.sph_geom[id], o, d, a, inv_a, RT_T_MIN, t_max, id == self, t);
+                        bool ok = hit_sphere(P.sph_geom[id], r, id == self, t);
                         if (STATS) cnt[RT_STAT_SPHERE]++;
                         if (ANY) {
                             if (ok) return true;
@@ -140,7 +168,7 @@ __device__ __forceinline__ bool bvh_traverse(const KernelParams &P, f3 o, f3 d, 
                     } else {
                         const uint32_t ti = id - P.n_bvh_spheres;
                         float t, b1, b2;
-                        bool ok = hit_tri(P.tri_geom[3 * ti], P.tri_geom[3 * ti + 1], P.tri_geom[3 * ti + 2], o, d, RT_T_MIN, t_max, t, b1, b2);
+                        bool ok = hit_tri(P.tri_geom[3 * ti], P.tri_geom[3 * ti + 1], P.tri_geom[3 * ti + 2], r, t, b1, b2);
                         if (STATS) cnt[RT_STAT_TRI]++;
                         if (ANY) {
                             if (ok) return true;
@@ -151,7 +179,7 @@ __device__ __forceinline__ bool bvh_traverse(const KernelParams &P, f3 o, f3 d, 
                 }
             } else {
                 const uint32_t axis = cw >> RT_BVH_AXIS_SHIFT;
-                const float da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+                const float da = axis == 0 ? r.d.x : (axis == 1 ? r.d.y : r.d.z);
                 const uint32_t left = node + 1, right = first;
                 const bool right_first = da < 0.0f;
                 RT_STACK_AT(sp) = right_first ? left : right;
@@ -167,30 +195,43 @@ __device__ __forceinline__ bool bvh_traverse(const KernelParams &P, f3 o, f3 d, 
     return false;
 }
 
-template <bool STATS, bool BVH>
-__device__ __forceinline__ HitRec closest_hit(const KernelParams &P, f3 o, f3 d, uint32_t self, uint32_t *cnt, uint32_t *s_stack) {
+template <bool STATS, int MODE>
+__device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &r, uint32_t self, uint32_t *cnt, uint32_t *s_stack,
+                                              const rt_f4 *s_geom) {
     HitRec h;
-    h.t = __builtin_inff();
+    h.t = __uint_as_float(__float_as_uint(r.tmax) - 1u);  // largest float below tmax (tmax > 0)
     h.shape = RT_NONE;
     h.b1 = h.b2 = 0.0f;
-    const float a = dot(d, d);
-    const float inv_a = fast_rcp(a);
-    if (!BVH) {
+    if (MODE == MODE_LDS) {
+        // tracked negated: nbest = -h.t, starting just above -tmax, so "not (n < nbest)" <=> t <= best < tmax
+        float nbest = -h.t;
+        const float ntmin = -r.tmin;
+#pragma unroll 4
+        for (uint32_t i = 0; i < P.n_spheres; i++) {  // wave-uniform LDS address: broadcast read, VGPR operands
+            float n0, n1;
+            sphere_roots(s_geom[i], r, i == self, n0, n1);
+            const float n = (n0 < ntmin) ? n0 : n1;
+            const bool take = (n1 < ntmin) & !(n < nbest);
+            nbest = take ? n : nbest;
+            h.shape = take ? i : h.shape;
+        }
+        h.t = -nbest;
+    } else if (MODE == MODE_GLOBAL) {
         for (uint32_t i = 0; i < P.n_spheres; i++) {  // wave-uniform index: scalar loads
             float t;
-            bool ok = hit_sphere(P.sph_geom[i], o, d, a, inv_a, RT_T_MIN, RT_T_MAX, i == self, t);
+            bool ok = hit_sphere(P.sph_geom[i], r, i == self, t);
             RT_TAKE(ok, t, i, (void)0)
         }
     }
     for (uint32_t i = 0; i < P.n_planes; i++) {
         float t;
-        bool ok = hit_plane(P.pln_geom[4 * i], o, d, RT_T_MIN, RT_T_MAX, t);
+        bool ok = hit_plane(P.pln_geom[4 * i], r, t);
         RT_TAKE(ok, t, P.n_spheres + i, (void)0)
     }
-    if (!BVH) {
+    if (MODE != MODE_BVH) {
         for (uint32_t i = 0; i < P.n_tris; i++) {
             float t, b1, b2;
-            bool ok = hit_tri(P.tri_geom[3 * i], P.tri_geom[3 * i + 1], P.tri_geom[3 * i + 2], o, d, RT_T_MIN, RT_T_MAX, t, b1, b2);
+            bool ok = hit_tri(P.tri_geom[3 * i], P.tri_geom[3 * i + 1], P.tri_geom[3 * i + 2], r, t, b1, b2);
             RT_TAKE(ok, t, P.n_spheres + P.n_planes + i, (h.b1 = b1, h.b2 = b2))
         }
         if (STATS) {
@@ -198,53 +239,47 @@ __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, f3 o, f3 d,
             cnt[RT_STAT_TRI] += P.n_tris;
         }
     } else {
-        bvh_traverse<STATS, false>(P, o, d, a, inv_a, RT_T_MAX, self, h, cnt, s_stack);
+        bvh_traverse<STATS, false>(P, r, self, h, cnt, s_stack);
     }
     if (STATS) cnt[RT_STAT_PLANE] += P.n_planes;
     return h;
 }
 
-// extension: shadow-ray any-hit for the point-light mode: direction = light - p, occluded iff some
-// shape is hit with T_MIN < t < 1.
-template <bool STATS, bool BVH>
-__device__ __forceinline__ bool occluded(const KernelParams &P, f3 o, f3 d, uint32_t self, uint32_t *cnt, uint32_t *s_stack) {
-    const float a = dot(d, d);
-    const float inv_a = fast_rcp(a);
+// extension: shadow-ray any-hit for the point-light mode: the reference-style ray is (p, light - p),
+// occluded iff some shape is hit with T_MIN < t_ref < 1, i.e. T_MIN*|L-p| < t < |L-p| on the unit ray.
+template <bool STATS, int MODE>
+__device__ __forceinline__ bool occluded(const KernelParams &P, const Ray &r, uint32_t self, uint32_t *cnt, uint32_t *s_stack, const rt_f4 *s_geom) {
     bool occ = false;
     float t, b1, b2;
-    if (!BVH) {
-        for (uint32_t i = 0; i < P.n_spheres; i++) occ |= hit_sphere(P.sph_geom[i], o, d, a, inv_a, RT_T_MIN, 1.0f, i == self, t);
-        for (uint32_t i = 0; i < P.n_tris; i++)
-            occ |= hit_tri(P.tri_geom[3 * i], P.tri_geom[3 * i + 1], P.tri_geom[3 * i + 2], o, d, RT_T_MIN, 1.0f, t, b1, b2);
+    if (MODE != MODE_BVH) {
+        if (MODE == MODE_LDS) {
+            for (uint32_t i = 0; i < P.n_spheres; i++) occ |= hit_sphere(s_geom[i], r, i == self, t);
+        } else {
+            for (uint32_t i = 0; i < P.n_spheres; i++) occ |= hit_sphere(P.sph_geom[i], r, i == self, t);
+        }
+        for (uint32_t i = 0; i < P.n_tris; i++) occ |= hit_tri(P.tri_geom[3 * i], P.tri_geom[3 * i + 1], P.tri_geom[3 * i + 2], r, t, b1, b2);
         if (STATS) {
             cnt[RT_STAT_SPHERE] += P.n_spheres;
             cnt[RT_STAT_TRI] += P.n_tris;
         }
     }
-    for (uint32_t i = 0; i < P.n_planes; i++) occ |= hit_plane(P.pln_geom[4 * i], o, d, RT_T_MIN, 1.0f, t);
+    for (uint32_t i = 0; i < P.n_planes; i++) occ |= hit_plane(P.pln_geom[4 * i], r, t);
     if (STATS) cnt[RT_STAT_PLANE] += P.n_planes;
-    if (BVH && !occ) {
+    if (MODE == MODE_BVH && !occ) {
         HitRec dummy;
-        dummy.t = 1.0f;
+        dummy.t = r.tmax;
         dummy.shape = RT_NONE;
-        occ = bvh_traverse<STATS, true>(P, o, d, a, inv_a, 1.0f, self, dummy, cnt, s_stack);
+        occ = bvh_traverse<STATS, true>(P, r, self, dummy, cnt, s_stack);
     }
     return occ;
-}
-
-// Ray::background_color — ray.rs:89-93
-__device__ __forceinline__ f3 sky_color(f3 d) {
-    float t = 0.5f * (d.y * fast_rsq(dot(d, d)) + 1.0f);
-    float w = 1.0f - t;
-    return mk3(fmaf(0.5f, t, w), fmaf(0.7f, t, w), fmaf(1.0f, t, w));
 }
 
 // Lambertian/Metal::random_unit_vector — lambertian_diffuse.rs:39-45, metal.rs:31-37 (a first, then z).
 // v_sin_f32 / v_cos_f32 take their argument in revolutions, so a = TAU*xi needs no multiply.
 __device__ __forceinline__ f3 random_unit_vector(uint32_t h) {
-    float xa = rt_unit(h);
-    float z = fmaf(2.0f, rt_unit(rt_second(h)), -1.0f);
-    float r = fast_sqrt(fmaf(-z, z, 1.0f));
+    const float xa = rt_unit(h);
+    const float z = fmaf(2.0f, rt_unit(rt_second(h)), -1.0f);
+    const float r = fast_sqrt(fmaf(-z, z, 1.0f));
     return mk3(r * __builtin_amdgcn_cosf(xa), r * __builtin_amdgcn_sinf(xa), z);
 }
 
@@ -257,13 +292,31 @@ __device__ __forceinline__ uint32_t texture_wrap(float val, float scale, uint32_
     return uint32_t(w < 0 ? w + int32_t(bound) : w);
 }
 
-__device__ __forceinline__ float acos_f32(float x) { return acosf(x); }
+// what shading needs to know about the surface that was hit
+struct Surface {
+    f3 n;              // Shape::normal_at_position: (p - c)/r for spheres (sphere.rs:63-65), never flipped
+    f3 tm;             // scatter factor albedo/pi*3
+    float param;       // fuzziness | ior | texture scale
+    float r1;          // dielectric: ((1-ior)/(1+ior))^2
+    float inv_ior;     // dielectric: 1/ior
+    uint32_t kind;     // RTHIP_MAT_*
+    uint32_t mat;      // material index (texture / light terms are fetched from DevMaterial when needed)
+    float tu, tv, tw;  // sphere: (p-c).z, (p-c).x, (p-c).y/r for the texture coordinates (sphere.rs:67-73)
+};
 
 // One full pass over a pixel: generate_pixel (lib.rs:269-316) with project_ray (ray.rs:42-87) inlined.
-template <bool STATS, bool BVH, bool LIGHTS>
+template <bool STATS, int MODE, bool LIGHTS>
 __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
-    __shared__ uint32_t s_stack_mem[BVH ? RT_BVH_MAX_DEPTH * 256 : 1];
+    __shared__ uint32_t s_stack_mem[MODE == MODE_BVH ? RT_BVH_MAX_DEPTH * 256 : 1];
+    __shared__ rt_f4 s_geom_mem[MODE == MODE_LDS ? RT_LDS_SPHERES : 1];
+    __shared__ rt_f4 s_shade_mem[MODE == MODE_LDS ? 3 * RT_LDS_SPHERES : 1];
     uint32_t *s_stack = s_stack_mem;
+    const rt_f4 *s_geom = s_geom_mem;
+    if (MODE == MODE_LDS) {
+        for (uint32_t i = threadIdx.x; i < P.n_spheres; i += 256) s_geom_mem[i] = P.sph_geom[i];
+        for (uint32_t i = threadIdx.x; i < 3 * P.n_spheres; i += 256) s_shade_mem[i] = P.sph_shade[i];
+        __syncthreads();
+    }
     const uint32_t tiles_x = (P.width + 15u) >> 4;
     const uint32_t tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -285,20 +338,36 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
         const uint32_t pixel_index = y * P.width + x;
         const uint32_t pkey = rt_pixel_key(rt_seed_key(P.seed), pixel_index);
         const f3 cam_o = mk3(P.ox, P.oy, P.oz);
+        // direction through the pixel's lower-left corner: d00 + H*x/(W-1) + V*y/(H-1)   (camera.rs:46-48, lib.rs:282-285)
+        const float pu = float(x) * P.inv_wm1, pv = float(y) * P.inv_hm1;
+        const f3 pix_d = mk3(fmaf(P.vx, pv, fmaf(P.hx, pu, P.d00x)), fmaf(P.vy, pv, fmaf(P.hy, pu, P.d00y)), fmaf(P.vz, pv, fmaf(P.hz, pu, P.d00z)));
         f3 acc = mk3(0.0f, 0.0f, 0.0f);
         uint32_t s = 0;
-        uint32_t key, bounce;
-        uint32_t self = RT_NONE;  // shape the current ray starts on
-        f3 o, d, T;
+        uint32_t key0 = rt_counter(pkey, P.sample0, 0);  // RNG counter of the current path's slot 0
+        uint32_t key = key0;                             // ... and of the slot in use (advances by GOLDEN per segment)
+        uint32_t bounce;
+        uint32_t self;  // shape the current ray starts on
+        Ray r;
+        f3 T;
         f3 Ld = mk3(0.0f, 0.0f, 0.0f);  // extension: direct light gathered along the path (point-light mode)
+        // Ray::new with an un-normalised direction: keep the unit vector, fold |d| into the window
+        auto set_dir = [&](f3 nd) {
+            const float l2 = dot(nd, nd);
+            const float rl = fast_rsq(l2);
+            r.d = nd * rl;
+            const float len = l2 * rl;
+            r.tmin = RT_T_MIN * len;
+            r.tmax = RT_T_MAX * len;
+        };
         auto new_path = [&]() {
-            key = rt_counter(pkey, P.sample0 + s, 0);  // RNG counter of this path's slot 0
             // lib.rs:282-285: x jitter first
-            const uint32_t hj = rt_mix32(key);
-            float u = (float(x) + rt_unit(hj)) * P.inv_wm1;
-            float v = (float(y) + rt_unit(rt_second(hj))) * P.inv_hm1;
-            o = cam_o;  // camera.rs:43-50
-            d = mk3(fmaf(P.vx, v, fmaf(P.hx, u, P.d00x)), fmaf(P.vy, v, fmaf(P.hy, u, P.d00y)), fmaf(P.vz, v, fmaf(P.hz, u, P.d00z)));
+            const uint32_t hj = rt_mix32(key0);
+            key = key0;
+            // u = (x + xi)/(W-1) = x/(W-1) + xi/(W-1): the per-pixel part is loop-invariant (pix_d)
+            const float ju = rt_unit(hj) * P.inv_wm1;
+            const float jv = rt_unit(rt_second(hj)) * P.inv_hm1;
+            r.o = cam_o;  // camera.rs:43-50
+            set_dir(mk3(fmaf(P.vx, jv, fmaf(P.hx, ju, pix_d.x)), fmaf(P.vy, jv, fmaf(P.hy, ju, pix_d.y)), fmaf(P.vz, jv, fmaf(P.hz, ju, pix_d.z))));
             T = mk3(1.0f, 1.0f, 1.0f);
             bounce = 0;
             self = RT_NONE;
@@ -311,130 +380,142 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
             HitRec h;
             h.shape = RT_NONE;
             if (bounce != P.max_depth) {  // ray.rs:70-72: depth exhausted -> sky without a scene query
-                h = closest_hit<STATS, BVH>(P, o, d, self, cnt, s_stack);
+                h = closest_hit<STATS, MODE>(P, r, self, cnt, s_stack, s_geom);
                 cnt[RT_STAT_RAYS]++;
             }
-            if (h.shape == RT_NONE) {  // ray.rs:85
-                L = T * sky_color(d);
+            if (h.shape == RT_NONE) {  // ray.rs:85, background_color ray.rs:89-93 (the direction is already unit)
+                const float t = fmaf(0.5f, r.d.y, 0.5f);
+                const float w = 1.0f - t;
+                L = T * mk3(fmaf(0.5f, t, w), fmaf(0.7f, t, w), w + t);
                 done = true;
                 if (STATS) cnt[RT_STAT_SKY]++;
             } else {
-                const f3 p = fma3(d, h.t, o);  // ray.rs:30-32
-                // ---- shape-specific: normal, material, texture coordinates (sphere.rs:63-73) ----
-                f3 n;
-                uint32_t mat;
-                float tu = 0.0f, tv = 0.0f;
+                const f3 p = fma3(r.d, h.t, r.o);  // ray.rs:30-32
+                // ---- the surface: normal + material (collision.rs:29-43) ----
+                Surface sf;
                 if (h.shape < P.n_spheres) {
-                    rt_f4 g = P.sph_geom[h.shape];
-                    rt_f4 sh = P.sph_shade[h.shape];
-                    f3 pc = mk3(p.x - g.x, p.y - g.y, p.z - g.z);
-                    n = pc * sh.x;  // (p - c)/r
-                    mat = __float_as_uint(sh.y);
-                    tu = pc.z, tv = pc.x;  // stash for atan2; resolved below only for textures
-                    h.b1 = pc.y * sh.x;    // n.y/r... = (p-c).y / r
-                } else if (h.shape < P.n_spheres + P.n_planes) {
-                    const uint32_t i = h.shape - P.n_spheres;
-                    rt_f4 g0 = P.pln_geom[4 * i], g1 = P.pln_geom[4 * i + 1];
-                    n = mk3(g0.x, g0.y, g0.z);
-                    mat = __float_as_uint(g1.w);
+                    const rt_f4 *rec = (MODE == MODE_LDS) ? (s_shade_mem + 3 * h.shape) : (P.sph_shade + 3 * h.shape);
+                    const rt_f4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    const f3 pc = mk3(p.x - r0.x, p.y - r0.y, p.z - r0.z);
+                    sf.n = pc * r0.w;  // (p - c)/r
+                    sf.tm = mk3(r1.x, r1.y, r1.z);
+                    sf.param = r1.w;
+                    sf.kind = __float_as_uint(r2.x);
+                    sf.r1 = r2.y;
+                    sf.inv_ior = r2.z;
+                    sf.mat = __float_as_uint(r2.w);
+                    sf.tu = pc.z, sf.tv = pc.x, sf.tw = pc.y * r0.w;
                 } else {
-                    const uint32_t i = h.shape - P.n_spheres - P.n_planes;
-                    rt_f4 e1 = P.tri_geom[3 * i + 1], e2 = P.tri_geom[3 * i + 2];
-                    n = normalize(cross(mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z)));
-                    mat = __float_as_uint(P.tri_geom[3 * i].w);
+                    if (h.shape < P.n_spheres + P.n_planes) {
+                        const uint32_t i = h.shape - P.n_spheres;
+                        const rt_f4 g0 = P.pln_geom[4 * i];
+                        sf.n = mk3(g0.x, g0.y, g0.z);
+                        sf.mat = __float_as_uint(P.pln_geom[4 * i + 1].w);
+                    } else {
+                        const uint32_t i = h.shape - P.n_spheres - P.n_planes;
+                        const rt_f4 e1 = P.tri_geom[3 * i + 1], e2 = P.tri_geom[3 * i + 2];
+                        sf.n = normalize(cross(mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z)));
+                        sf.mat = __float_as_uint(P.tri_geom[3 * i].w);
+                    }
+                    const DevMaterial m = P.materials[sf.mat];
+                    sf.tm = mk3(m.tr, m.tg, m.tb);
+                    sf.param = m.param, sf.kind = m.kind, sf.r1 = m.r1, sf.inv_ior = m.inv_ior;
+                    sf.tu = sf.tv = sf.tw = 0.0f;
                 }
-                const DevMaterial m = P.materials[mat];
-                const uint32_t hb = rt_mix32(key + (1u + bounce) * RT_RNG_GOLDEN);  // RNG slot 1 + bounce
                 if (STATS) {
 #pragma unroll
-                    for (uint32_t kk = 0; kk < 4; kk++) cnt[RT_STAT_HIT0 + kk] += (m.kind == kk) ? 1u : 0u;
+                    for (uint32_t kk = 0; kk < 4; kk++) cnt[RT_STAT_HIT0 + kk] += (sf.kind == kk) ? 1u : 0u;
                 }
-                if (m.kind == RTHIP_MAT_TEXTURE) {
+                if (sf.kind == RTHIP_MAT_TEXTURE) {
                     // Texture::scatter — texture.rs:45-57; bounce -> None (texture.rs:59-61) => path ends, ray.rs:80
                     float U, V;
                     if (h.shape < P.n_spheres) {
-                        U = (1.0f + atan2f(tu, tv) * 0.31830988618379067f) * 0.5f;  // sphere.rs:70
-                        V = acos_f32(h.b1) * 0.31830988618379067f;                  // sphere.rs:71
+                        U = (1.0f + atan2f(sf.tu, sf.tv) * 0.31830988618379067f) * 0.5f;  // sphere.rs:70
+                        V = acosf(sf.tw) * 0.31830988618379067f;                          // sphere.rs:71
                     } else if (h.shape < P.n_spheres + P.n_planes) {
                         const uint32_t i = h.shape - P.n_spheres;
-                        rt_f4 g1 = P.pln_geom[4 * i + 1], g2 = P.pln_geom[4 * i + 2], g3 = P.pln_geom[4 * i + 3];
-                        f3 r = mk3(p.x - g1.x, p.y - g1.y, p.z - g1.z);
-                        U = dot(r, mk3(g2.x, g2.y, g2.z));
-                        V = dot(r, mk3(g3.x, g3.y, g3.z));
+                        const rt_f4 g1 = P.pln_geom[4 * i + 1], g2 = P.pln_geom[4 * i + 2], g3 = P.pln_geom[4 * i + 3];
+                        const f3 q = mk3(p.x - g1.x, p.y - g1.y, p.z - g1.z);
+                        U = dot(q, mk3(g2.x, g2.y, g2.z));
+                        V = dot(q, mk3(g3.x, g3.y, g3.z));
                     } else {
                         U = h.b1, V = h.b2;
                     }
-                    const DevTexInfo ti = P.tex_info[m.texture];
-                    uint32_t txl = texture_wrap(U, m.param, ti.width);
-                    uint32_t tyl = texture_wrap(V, m.param, ti.height);
-                    uint32_t texel = P.texels[ti.first_texel + (((tyl >> 3) * ti.tiles_per_row + (txl >> 3)) << 6) + ((tyl & 7u) << 3) + (txl & 7u)];
-                    f3 c = mk3(float(texel & 255u), float((texel >> 8) & 255u), float((texel >> 16) & 255u)) * (1.0f / 255.0f);
+                    const DevTexInfo ti = P.tex_info[P.materials[sf.mat].texture];
+                    const uint32_t txl = texture_wrap(U, sf.param, ti.width);
+                    const uint32_t tyl = texture_wrap(V, sf.param, ti.height);
+                    const uint32_t texel = P.texels[ti.first_texel + (((tyl >> 3) * ti.tiles_per_row + (txl >> 3)) << 6) + ((tyl & 7u) << 3) + (txl & 7u)];
+                    const f3 c = mk3(float(texel & 255u), float((texel >> 8) & 255u), float((texel >> 16) & 255u)) * (1.0f / 255.0f);
                     L = T * c;
                     done = true;
                 } else {
-                    if (LIGHTS && m.kind != RTHIP_MAT_DIELECTRIC) {
+                    const float cosi = dot(r.d, sf.n);
+                    const f3 refl = fma3(sf.n, -2.0f * cosi, r.d);  // metal.rs:27-29, dielectric.rs:28-30 (unit incoming direction)
+                    if (LIGHTS && sf.kind != RTHIP_MAT_DIELECTRIC) {
                         // extension (RTHIP_F_POINT_LIGHTS): Lambert N.L on Lambertian, Phong (R.L)^s on Metal, one shadow ray per light
+                        const DevMaterial m = P.materials[sf.mat];
                         f3 sum = mk3(0.0f, 0.0f, 0.0f);
-                        const f3 dhl = normalize(d);
-                        const f3 rl = fma3(n, -2.0f * dot(dhl, n), dhl);
                         for (uint32_t li = 0; li < P.n_lights; li++) {
                             const DevLight lt = P.lights[li];
                             const f3 to_light = mk3(lt.px - p.x, lt.py - p.y, lt.pz - p.z);
                             const float dist2 = dot(to_light, to_light);
-                            const f3 ldir = to_light * fast_rsq(dist2);
+                            const float rdist = fast_rsq(dist2);
+                            const f3 ldir = to_light * rdist;
                             float w;
-                            if (m.kind == RTHIP_MAT_LAMBERTIAN)
-                                w = fmaxf(0.0f, dot(n, ldir));
+                            if (sf.kind == RTHIP_MAT_LAMBERTIAN)
+                                w = fmaxf(0.0f, dot(sf.n, ldir));
                             else
-                                w = (m.shininess > 0.0f) ? __powf(fmaxf(0.0f, dot(rl, ldir)), m.shininess) : 0.0f;
+                                w = (m.shininess > 0.0f) ? __powf(fmaxf(0.0f, dot(refl, ldir)), m.shininess) : 0.0f;
                             if (w > 0.0f) {
                                 cnt[RT_STAT_RAYS]++;
                                 if (STATS) cnt[RT_STAT_SHADOW]++;
-                                if (!occluded<STATS, BVH>(P, p, to_light, h.shape, cnt, s_stack)) {
-                                    const float s = w * fast_rcp(dist2);
-                                    sum = sum + mk3(m.ar * lt.ir, m.ag * lt.ig, m.ab * lt.ib) * s;
+                                Ray sr;
+                                sr.o = p, sr.d = ldir;
+                                const float dist = dist2 * rdist;
+                                sr.tmin = RT_T_MIN * dist, sr.tmax = dist;
+                                if (!occluded<STATS, MODE>(P, sr, h.shape, cnt, s_stack, s_geom)) {
+                                    const float sc = w * fast_rcp(dist2);
+                                    sum = sum + mk3(m.ar * lt.ir, m.ag * lt.ig, m.ab * lt.ib) * sc;
                                 }
                             }
                         }
                         Ld = Ld + T * sum;
                     }
-                    T = T * mk3(m.tr, m.tg, m.tb);  // scatter: albedo/pi * 3 (lambertian_diffuse.rs:53-66, metal.rs:45-56, dielectric.rs:56-66)
-                    f3 nd;
-                    done = false;
-                    if (m.kind == RTHIP_MAT_LAMBERTIAN) {
-                        nd = n + random_unit_vector(hb);  // lambertian_diffuse.rs:68-73
-                    } else {
-                        const f3 dh = normalize(d);
-                        const f3 refl = fma3(n, -2.0f * dot(dh, n), dh);  // metal.rs:27-29, dielectric.rs:28-30
-                        if (m.kind == RTHIP_MAT_METAL) {
-                            nd = fma3(random_unit_vector(hb), m.param, refl);  // metal.rs:59-60
-                            if (dot(nd, n) < 0.0f) {                                   // metal.rs:62-64 -> None -> ray.rs:80
-                                L = T;
-                                done = true;
-                            }
-                        } else {  // dielectric.rs:68-98
-                            const float dp = dot(d, n);
-                            const bool inside = dp > 0.0f;
-                            const f3 on = inside ? -n : n;
-                            const float eta = inside ? m.param : m.inv_ior;
-                            // `direction().len()` is the element count 3: dielectric.rs:78,82
-                            const float cosine = (inside ? m.param * dp : -dp) * (1.0f / 3.0f);
-                            const float dt = dot(dh, on);
-                            const float k = fmaf(-eta * eta, fmaf(-dt, dt, 1.0f), 1.0f);  // dielectric.rs:39
-                            const float om = 1.0f - cosine;
-                            const float om2 = om * om;
-                            const float prob = (k < 0.0f) ? 1.0f : fmaf(1.0f - m.r1, om2 * om2 * om, m.r1);  // dielectric.rs:47-52,87-92
-                            const float xi = rt_unit(hb);                                             // dielectric.rs:94
-                            if (prob > xi) {
-                                nd = refl;
-                            } else {
-                                const f3 perp = fma3(on, -dt, dh);  // dielectric.rs:44
-                                nd = fma3(on, -fast_sqrt(k), perp * eta);
-                            }
-                        }
+                    T = T * sf.tm;  // scatter: albedo/pi * 3 (lambertian_diffuse.rs:53-66, metal.rs:45-56, dielectric.rs:56-66)
+                    key += RT_RNG_GOLDEN;
+                    const uint32_t hb = rt_mix32(key);  // RNG slot 1 + bounce
+                    // Lambertian: n + w (lambertian_diffuse.rs:68-73); Metal: reflect + fuzz*w (metal.rs:59-60): one shared unit vector
+                    const f3 w = random_unit_vector(hb);
+                    const bool lambert = sf.kind == RTHIP_MAT_LAMBERTIAN;
+                    const f3 base = lambert ? sf.n : refl;
+                    const float wf = lambert ? 1.0f : sf.param;
+                    f3 nd = fma3(w, wf, base);
+                    // metal.rs:62-64: absorbed if the new direction points into the surface (never true for n + w)
+                    done = dot(nd, sf.n) < 0.0f;
+                    if (sf.kind == RTHIP_MAT_DIELECTRIC) {  // dielectric.rs:68-98
+                        // dot_product = direction . normal with the UN-normalised direction; len() is the element count 3: dielectric.rs:74-83
+                        const float len = r.tmin * (1.0f / RT_T_MIN);  // |direction|
+                        const float dp = cosi * len;
+                        const bool inside = dp > 0.0f;
+                        const float eta = inside ? sf.param : sf.inv_ior;
+                        const float cosine = (inside ? sf.param * dp : -dp) * (1.0f / 3.0f);
+                        // outward_normal = inside ? -n : n, so unit . outward_normal = -|cosi|
+                        const float dt = -fabsf(cosi);
+                        const float k = fmaf(-eta * eta, fmaf(-dt, dt, 1.0f), 1.0f);  // dielectric.rs:39
+                        const float om = 1.0f - cosine;
+                        const float om2 = om * om;
+                        const float prob = (k < 0.0f) ? 1.0f : fmaf(1.0f - sf.r1, om2 * om2 * om, sf.r1);  // dielectric.rs:47-52,87-92
+                        const float xi = rt_unit(hb);                                                      // dielectric.rs:94
+                        // refracted = (unit - on*dt)*eta - on*sqrt(k)   (dielectric.rs:44)
+                        const float sgn = inside ? -1.0f : 1.0f;
+                        const float cn = sgn * (-dt * eta - fast_sqrt(k));
+                        const f3 refr = fma3(sf.n, cn, r.d * eta);
+                        nd = (prob > xi) ? refl : refr;
+                        done = false;
                     }
-                    o = p;
-                    d = nd;
+                    if (done) L = T;  // None -> new_color alone, ray.rs:80
+                    r.o = p;
+                    set_dir(nd);
                     self = h.shape;
                     bounce++;
                 }
@@ -445,6 +526,7 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                 cnt[RT_STAT_PATHS]++;
                 s++;
                 if (s == P.spp) break;
+                key0 += RT_RNG_SLOTS * RT_RNG_GOLDEN;
                 new_path();
             }
         }
@@ -465,10 +547,10 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
         }
         if (P.rgba8) {
             // mean, clamp(0,1), sqrt, *255, `as u8` (truncate, saturate, NaN -> 0): lib.rs:294-299,30-38
-            float r = __fsqrt_rn(fminf(fmaxf(acc.x * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
-            float g = __fsqrt_rn(fminf(fmaxf(acc.y * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
-            float b = __fsqrt_rn(fminf(fmaxf(acc.z * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
-            P.rgba8[oi] = uint32_t(r) | (uint32_t(g) << 8) | (uint32_t(b) << 16) | 0xff000000u;
+            float cr = __fsqrt_rn(fminf(fmaxf(acc.x * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
+            float cg = __fsqrt_rn(fminf(fmaxf(acc.y * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
+            float cb = __fsqrt_rn(fminf(fmaxf(acc.z * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
+            P.rgba8[oi] = uint32_t(cr) | (uint32_t(cg) << 8) | (uint32_t(cb) << 16) | 0xff000000u;
         }
     }
 
@@ -488,19 +570,31 @@ __global__ void pick_kernel(const KernelParams P, float u, float v, long long *o
     __shared__ uint32_t s_stack[RT_BVH_MAX_DEPTH * 256];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t cnt[RT_STAT_N];
-    f3 o = mk3(P.ox, P.oy, P.oz);
-    f3 d = mk3(fmaf(P.vx, v, fmaf(P.hx, u, P.d00x)), fmaf(P.vy, v, fmaf(P.hy, u, P.d00y)), fmaf(P.vz, v, fmaf(P.hz, u, P.d00z)));
-    HitRec h = P.n_bvh_nodes ? closest_hit<false, true>(P, o, d, RT_NONE, cnt, s_stack) : closest_hit<false, false>(P, o, d, RT_NONE, cnt, s_stack);
+    Ray r;
+    r.o = mk3(P.ox, P.oy, P.oz);
+    const f3 nd = mk3(fmaf(P.vx, v, fmaf(P.hx, u, P.d00x)), fmaf(P.vy, v, fmaf(P.hy, u, P.d00y)), fmaf(P.vz, v, fmaf(P.hz, u, P.d00z)));
+    const float l2 = dot(nd, nd), rl = fast_rsq(l2);
+    r.d = nd * rl;
+    r.tmin = RT_T_MIN * (l2 * rl), r.tmax = RT_T_MAX * (l2 * rl);
+    HitRec h = P.n_bvh_nodes ? closest_hit<false, MODE_BVH>(P, r, RT_NONE, cnt, s_stack, nullptr)
+                             : closest_hit<false, MODE_GLOBAL>(P, r, RT_NONE, cnt, s_stack, nullptr);
     *out = (h.shape == RT_NONE) ? -1ll : (long long)h.shape;
 }
 
 // ---- launch wrappers (called from rthip_api.cpp) -----------------------------------------
-template <bool STATS, bool BVH>
+template <bool STATS, int MODE>
 static void launch_variant(const KernelParams &P, bool lights, uint32_t blocks, hipStream_t stream) {
     if (lights)
-        hipLaunchKernelGGL((render_kernel<STATS, BVH, true>), dim3(blocks), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((render_kernel<STATS, MODE, true>), dim3(blocks), dim3(256), 0, stream, P);
     else
-        hipLaunchKernelGGL((render_kernel<STATS, BVH, false>), dim3(blocks), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((render_kernel<STATS, MODE, false>), dim3(blocks), dim3(256), 0, stream, P);
+}
+
+template <bool STATS>
+static void launch_mode(const KernelParams &P, int mode, bool lights, uint32_t blocks, hipStream_t stream) {
+    if (mode == MODE_BVH) launch_variant<STATS, MODE_BVH>(P, lights, blocks, stream);
+    else if (mode == MODE_LDS) launch_variant<STATS, MODE_LDS>(P, lights, blocks, stream);
+    else launch_variant<STATS, MODE_GLOBAL>(P, lights, blocks, stream);
 }
 
 extern "C" hipError_t rt_launch_render(const KernelParams *P, int count_stats, hipStream_t stream) {
@@ -508,14 +602,9 @@ extern "C" hipError_t rt_launch_render(const KernelParams *P, int count_stats, h
     const uint32_t blocks = tiles_x * tiles_y;
     if (blocks == 0) return hipSuccess;
     const bool lights = (P->flags & RTHIP_F_POINT_LIGHTS) && P->n_lights > 0;
-    const bool bvh = P->n_bvh_nodes > 0;
-    if (count_stats) {
-        if (bvh) launch_variant<true, true>(*P, lights, blocks, stream);
-        else launch_variant<true, false>(*P, lights, blocks, stream);
-    } else {
-        if (bvh) launch_variant<false, true>(*P, lights, blocks, stream);
-        else launch_variant<false, false>(*P, lights, blocks, stream);
-    }
+    const int mode = P->n_bvh_nodes > 0 ? MODE_BVH : (P->n_spheres <= RT_LDS_SPHERES ? MODE_LDS : MODE_GLOBAL);
+    if (count_stats) launch_mode<true>(*P, mode, lights, blocks, stream);
+    else launch_mode<false>(*P, mode, lights, blocks, stream);
     return hipGetLastError();
 }
 

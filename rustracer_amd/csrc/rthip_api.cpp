@@ -299,14 +299,37 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
         ctx->have_scene = false;
         const double PI = 3.14159265358979323846264338327950288;
 
-        // ---- spheres: geom {c, r^2}, shade {1/r, material} ----
-        std::vector<rt_f4> geom(s->n_spheres), shade(s->n_spheres);
+        int st;
+        // ---- materials ----
+        std::vector<DevMaterial> mats(s->n_materials);
+        for (uint64_t i = 0; i < s->n_materials; i++) {
+            const rthip_material &m = s->materials[i];
+            DevMaterial &d = mats[i];
+            std::memset(&d, 0, sizeof d);
+            // constructors store albedo/PI (lambertian_diffuse.rs:21, metal.rs:21, dielectric.rs:22); scatter multiplies by 3.0
+            d.ar = float(m.albedo[0] / PI), d.ag = float(m.albedo[1] / PI), d.ab = float(m.albedo[2] / PI);
+            d.tr = float(m.albedo[0] / PI * 3.0), d.tg = float(m.albedo[1] / PI * 3.0), d.tb = float(m.albedo[2] / PI * 3.0);
+            d.param = float(m.param);
+            d.kind = m.kind;
+            d.texture = m.texture;
+            d.shininess = float(m.shininess);
+            if (m.kind == RTHIP_MAT_DIELECTRIC) {
+                double r0 = (1.0 - m.param) / (1.0 + m.param);  // dielectric.rs:48
+                d.r1 = float(r0 * r0);
+                d.inv_ior = float(1.0 / m.param);  // dielectric.rs:81
+            }
+        }
+        if ((st = upload(ctx, ctx->materials, mats.data(), mats.size() * sizeof(DevMaterial)))) return st;
+        // ---- spheres: geom {c, r^2}; shading record 3 x float4 {c, 1/r} {albedo/pi*3, param} {kind, r1, 1/ior, material} ----
+        std::vector<rt_f4> geom(s->n_spheres), shade(3 * s->n_spheres);
         for (uint64_t i = 0; i < s->n_spheres; i++) {
             const rthip_sphere &sp = s->spheres[i];
+            const DevMaterial &m = mats[sp.material];
             geom[i] = f4(sp.center[0], sp.center[1], sp.center[2], sp.radius * sp.radius);
-            shade[i] = rt_f4{float(1.0 / sp.radius), bits_f(sp.material), float(sp.radius), 0.0f};
+            shade[3 * i + 0] = f4(sp.center[0], sp.center[1], sp.center[2], 1.0 / sp.radius);
+            shade[3 * i + 1] = rt_f4{m.tr, m.tg, m.tb, m.param};
+            shade[3 * i + 2] = rt_f4{bits_f(m.kind), m.r1, m.inv_ior, bits_f(sp.material)};
         }
-        int st;
         if ((st = upload(ctx, ctx->sph_geom, geom.data(), geom.size() * sizeof(rt_f4)))) return st;
         if ((st = upload(ctx, ctx->sph_shade, shade.data(), shade.size() * sizeof(rt_f4)))) return st;
         // ---- planes: {n, n.p0} {p0, material} {tu} {tv} ----
@@ -335,26 +358,6 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
             tr[3 * i + 2] = rt_f4{v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2], 0.0f};
         }
         if ((st = upload(ctx, ctx->tri_geom, tr.data(), tr.size() * sizeof(rt_f4)))) return st;
-        // ---- materials ----
-        std::vector<DevMaterial> mats(s->n_materials);
-        for (uint64_t i = 0; i < s->n_materials; i++) {
-            const rthip_material &m = s->materials[i];
-            DevMaterial &d = mats[i];
-            std::memset(&d, 0, sizeof d);
-            // constructors store albedo/PI (lambertian_diffuse.rs:21, metal.rs:21, dielectric.rs:22); scatter multiplies by 3.0
-            d.ar = float(m.albedo[0] / PI), d.ag = float(m.albedo[1] / PI), d.ab = float(m.albedo[2] / PI);
-            d.tr = float(m.albedo[0] / PI * 3.0), d.tg = float(m.albedo[1] / PI * 3.0), d.tb = float(m.albedo[2] / PI * 3.0);
-            d.param = float(m.param);
-            d.kind = m.kind;
-            d.texture = m.texture;
-            d.shininess = float(m.shininess);
-            if (m.kind == RTHIP_MAT_DIELECTRIC) {
-                double r0 = (1.0 - m.param) / (1.0 + m.param);  // dielectric.rs:48
-                d.r1 = float(r0 * r0);
-                d.inv_ior = float(1.0 / m.param);  // dielectric.rs:81
-            }
-        }
-        if ((st = upload(ctx, ctx->materials, mats.data(), mats.size() * sizeof(DevMaterial)))) return st;
         // ---- textures: RGB8 -> RGBA8 in 8x8-texel tiles (a wave's nearby UVs touch few 256-B tiles) ----
         std::vector<DevTexInfo> ti(s->n_textures);
         size_t total_texels = 0;
