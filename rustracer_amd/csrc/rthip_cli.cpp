@@ -1,0 +1,65 @@
+// rthip_cli.cpp — C++ front-end on the drop-in surface (raytracer_hip.hpp over include/rthip.h): builds the
+// reference's standalone scene (standalone/src/main.rs:66-89) with the mirrored constructors, renders it
+// on the GPU through a PixelRenderer (the `World` framebuffer of standalone/src/renderers/pixels.rs:205-262,
+// reduced to a byte buffer), writes a PPM and prints one JSON line of statistics.
+//   rthip_cli [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--texture path.rgb8.z] [--out image.ppm]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "raytracer_hip.hpp"
+
+using namespace raytracer_hip;
+
+struct World : PixelRenderer {  // standalone/src/renderers/pixels.rs:205-262
+    uint32_t width, height;
+    std::vector<uint8_t> pixels;  // y-up RGBA8
+    uint64_t writes = 0;
+    World(uint32_t w, uint32_t h) : width(w), height(h), pixels(size_t(w) * h * 4, 0) {}
+    void set_pixel(PixelPosition pos, PixelColor c) override {
+        uint8_t *p = &pixels[(pos.y * width + pos.x) * 4];
+        p[0] = c.r, p[1] = c.g, p[2] = c.b, p[3] = 255;
+        writes++;
+    }
+    void invalidate_pixels() override { std::fill(pixels.begin(), pixels.end(), 0); }
+};
+
+int main(int argc, char **argv) {
+    uint32_t width = 960, height = 540, spp = 16, depth = 50, seed = 1;  // standalone/src/main.rs:51-52, ray.rs:44
+    std::string out, texture = "tests/golden/textures/bergsjostolen.rgb8.z";
+    for (int i = 1; i + 1 < argc; i += 2) {
+        std::string k = argv[i];
+        if (k == "--width") width = std::atoi(argv[i + 1]);
+        else if (k == "--height") height = std::atoi(argv[i + 1]);
+        else if (k == "--spp") spp = std::atoi(argv[i + 1]);
+        else if (k == "--depth") depth = std::atoi(argv[i + 1]);
+        else if (k == "--seed") seed = std::atoi(argv[i + 1]);
+        else if (k == "--texture") texture = argv[i + 1];
+        else if (k == "--out") out = argv[i + 1];
+        else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
+    }
+    try {
+        Scene scene = {
+            Sphere::create({-1.01, 0.0, -1.0}, 0.5, Dielectric::create({1.0, 0.8, 0.80}, 1.05)),
+            Sphere::create({0.0, -100.5, -1.0}, 100.0, Lambertian::new_from_hex(0x007070)),
+            Sphere::create({1.0, 0.0, -1.0}, 0.5, Metal::create({0.8, 0.8, 0.8}, 0.1)),
+            Sphere::create({-0.0, 0.0, -1.0}, 0.5, Texture::load_from_file(texture, 1.0)),
+        };
+        SceneDesc desc(scene);
+        HipRaytracer rt(width, height, seed);
+        rt.upload(desc);
+        World world(width, height);
+        rthip_stats st = rt.render(spp, depth, &world);
+        int64_t centre = rt.get_shape((width - 1) * 0.5, (height - 1) * 0.5);
+        if (!out.empty()) write_ppm_p3(out, world.pixels, width, height);
+        std::printf("{\"width\": %u, \"height\": %u, \"spp\": %u, \"max_depth\": %u, \"paths\": %llu, \"rays\": %llu, \"kernel_ms\": %.3f, "
+                    "\"d2h_ms\": %.3f, \"mrays_per_s\": %.1f, \"set_pixel_calls\": %llu, \"shape_at_centre\": %lld}\n",
+                    width, height, spp, depth, (unsigned long long)st.paths, (unsigned long long)st.rays, st.kernel_ms, st.d2h_ms,
+                    st.rays / st.kernel_ms / 1e3, (unsigned long long)world.writes, (long long)centre);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "rthip_cli: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

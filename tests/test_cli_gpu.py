@@ -1,0 +1,34 @@
+"""The C++ front-end (rustracer_amd/csrc/rthip_cli, built on raytracer_hip.hpp) drives the same C ABI as the Python
+layer: its PPM must be byte-identical to the Python render of the same scene/seed, and it exercises the
+PixelRenderer::set_pixel hand-off and the PPM writer (row order of standalone/src/renderers/ppm.rs:28-35)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rustracer_amd import Raytracer, presets
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "rustracer_amd", "csrc", "rthip_cli")
+
+
+def test_cli_matches_python_layer(tmp_path):
+    assert os.path.exists(CLI), "build first: __graft_entry__.build()"
+    w, h, spp, depth, seed = 200, 112, 3, 50, 9
+    out = tmp_path / "img.ppm"
+    r = subprocess.run([CLI, "--width", str(w), "--height", str(h), "--spp", str(spp), "--depth", str(depth), "--seed", str(seed),
+                        "--texture", presets.texture_path("bergsjostolen"), "--out", str(out)], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout)
+    assert info["paths"] == w * h * spp and info["set_pixel_calls"] == w * h and info["shape_at_centre"] == 3
+    tok = out.read_text().split()
+    assert tok[0] == "P3" and (int(tok[1]), int(tok[2]), int(tok[3])) == (w, h, 255)
+    ppm = np.array(tok[4:], dtype=np.uint8).reshape(h, w, 3)
+    rt = Raytracer.new(w, h, seed=seed)
+    res = rt.render(presets.standalone_scene(), spp, max_depth=depth)
+    assert info["rays"] == res.stats["rays"]
+    assert np.array_equal(ppm, res.rgba8[::-1, :, :3])  # the PPM is written top row first
+    rt.close()
