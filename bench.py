@@ -147,7 +147,7 @@ def main():
             },
             "roofline": {
                 "bound": "valu_fp32",
-                "kernel": "render_kernel<false>",
+                "kernel": "render_kernel<STATS=false, MODE_LDS, LIGHTS=false>",
                 "achieved": round(achieved, 3),
                 "peak": FP32_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
@@ -174,17 +174,18 @@ def cpu_baseline(flat):
     from rustracer_amd import make_params
     cam = oracle.camera_lookat(-1.8, 1.0, 2.0)
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, oracle.hw_threads())
-    p1 = make_params(WIDTH, HEIGHT, 1, MAX_DEPTH, 1)
+    spp1, sppn = 8, 8 * threads
+    p1 = make_params(WIDTH, HEIGHT, spp1, MAX_DEPTH, 1)
     _, _, st1, s1 = oracle.render(flat, cam, p1, precision=64, threads=1)
-    pn = make_params(WIDTH, HEIGHT, 8, MAX_DEPTH, 1)
+    pn = make_params(WIDTH, HEIGHT, sppn, MAX_DEPTH, 1)
     _, _, stn, sn = oracle.render(flat, cam, pn, precision=64, threads=threads)
     return {
         "value": round(stn["rays"] / sn / 1e6, 2),
         "unit": "Mrays/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"full {WIDTH}x{HEIGHT} frame, max_depth {MAX_DEPTH}, f64 oracle: 8 spp on {threads} threads ({sn:.2f} s); "
-                  f"1 spp on 1 thread ({s1:.2f} s) — the reference itself renders on one thread",
+        "sample": f"full {WIDTH}x{HEIGHT} frame, max_depth {MAX_DEPTH}, f64 oracle: {sppn} spp on {threads} threads ({sn:.1f} s); "
+                  f"{spp1} spp on 1 thread ({s1:.1f} s) — the reference itself renders on one thread",
         "value_1thread": round(st1["rays"] / s1 / 1e6, 2),
     }
 
