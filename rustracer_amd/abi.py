@@ -101,7 +101,7 @@ SYMBOLS = {
 }
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librthip.so")
+LIB_PATH = os.environ.get("RTHIP_LIB") or os.path.join(_HERE, "csrc", "librthip.so")  # RTHIP_LIB: A/B builds of the same ABI
 
 _lib = None
 

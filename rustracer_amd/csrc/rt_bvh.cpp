@@ -3,8 +3,9 @@
 // what that scan returns, including the "later index wins on equal t" rule, see rt_kernels.hip).
 //
 // Binned-SAH top-down build over the FLOAT primitives the device will test (so the boxes bound what
-// the kernel intersects), leaves of <= RT_BVH_LEAF primitives, depth-first node order:
-// left child = node + 1, right child = node.first (inner nodes have count == 0).
+// the kernel intersects), leaves of <= RT_BVH_LEAF primitives. Emitted as 64-byte nodes that hold
+// the boxes of BOTH children plus a reference to each (DevBvhNode: one fetch decides both
+// descents), leaves being references into the BVH-ordered primitive array `prims`.
 // Depth is capped at RT_BVH_MAX_DEPTH (the traversal stack lives in LDS) by switching to median
 // splits when a subtree could otherwise exceed it.
 #include "rt_bvh.h"
@@ -38,25 +39,24 @@ struct Builder {
     std::vector<float> centroid; // 3 per primitive
     std::vector<uint32_t> &prims;
     std::vector<DevBvhNode> &nodes;
+    uint32_t levels = 0;  // inner nodes on the deepest root-to-leaf path = stack levels the traversal needs
     Builder(std::vector<uint32_t> &p, std::vector<DevBvhNode> &n) : prims(p), nodes(n) {}
 
     static constexpr int BINS = 16;
 
-    uint32_t build(uint32_t begin, uint32_t end, int depth) {
-        const uint32_t me = uint32_t(nodes.size());
-        nodes.emplace_back();
-        Box b, cb;
+    // returns the reference of the subtree over prims[begin, end) and its box
+    uint32_t build(uint32_t begin, uint32_t end, int depth, Box &b) {
+        Box cb;
         b.reset(), cb.reset();
         for (uint32_t i = begin; i < end; i++) {
             b.grow(pbox[prims[i]]);
             cb.grow_pt(&centroid[3 * size_t(prims[i])]);
         }
-        for (int k = 0; k < 3; k++) nodes[me].lo[k] = b.lo[k], nodes[me].hi[k] = b.hi[k];
         const uint32_t n = end - begin;
-        if (n <= RT_BVH_LEAF) {
-            nodes[me].first = begin, nodes[me].count = n;
-            return me;
-        }
+        if (n <= RT_BVH_LEAF) return RT_BVH_LEAF_BIT | (begin << 2) | (n - 1u);
+        const uint32_t me = uint32_t(nodes.size());
+        nodes.emplace_back();
+        levels = std::max(levels, uint32_t(depth) + 1u);
         // pick the split
         uint32_t mid = begin + n / 2;
         bool use_median = false;
@@ -124,10 +124,12 @@ struct Builder {
                 return ca < cc || (ca == cc && a < c);
             });
         }
-        build(begin, mid, depth + 1);  // left child is me + 1
-        uint32_t right = build(mid, end, depth + 1);
-        nodes[me].first = right;
-        nodes[me].count = uint32_t(axis) << RT_BVH_AXIS_SHIFT;
+        Box lb, rb;
+        const uint32_t lref = build(begin, mid, depth + 1, lb);
+        const uint32_t rref = build(mid, end, depth + 1, rb);
+        DevBvhNode &nd = nodes[me];
+        for (int k = 0; k < 3; k++) nd.lo0[k] = lb.lo[k], nd.hi0[k] = lb.hi[k], nd.lo1[k] = rb.lo[k], nd.hi1[k] = rb.hi[k];
+        nd.ref0 = lref, nd.ref1 = rref, nd._pad0 = nd._pad1 = 0;
         return me;
     }
 };
@@ -137,11 +139,11 @@ inline float next_up(float x) { return std::nextafter(x, INFINITY); }
 
 }  // namespace
 
-void rt_build_bvh(const rthip_scene_desc *s, std::vector<DevBvhNode> &nodes, std::vector<uint32_t> &prims) {
+uint32_t rt_build_bvh(const rthip_scene_desc *s, std::vector<DevBvhNode> &nodes, std::vector<uint32_t> &prims) {
     nodes.clear();
     prims.clear();
     const size_t ns = s->n_spheres, nt = s->n_triangles, n = ns + nt;
-    if (n == 0) return;
+    if (n == 0) return 0;
     Builder B(prims, nodes);
     B.pbox.resize(n);
     B.centroid.resize(3 * n);
@@ -173,6 +175,16 @@ void rt_build_bvh(const rthip_scene_desc *s, std::vector<DevBvhNode> &nodes, std
     }
     prims.resize(n);
     std::iota(prims.begin(), prims.end(), 0u);
-    nodes.reserve(2 * n / RT_BVH_LEAF + 16);
-    B.build(0, uint32_t(n), 0);
+    nodes.reserve(n / 2 + 16);
+    Box root;
+    const uint32_t ref = B.build(0, uint32_t(n), 0, root);
+    if (ref & RT_BVH_LEAF_BIT) {
+        // a single leaf: give it a root node whose second child is an empty (inverted, never hit) box
+        DevBvhNode nd;
+        for (int k = 0; k < 3; k++) nd.lo0[k] = root.lo[k], nd.hi0[k] = root.hi[k], nd.lo1[k] = INFINITY, nd.hi1[k] = -INFINITY;
+        nd.ref0 = ref, nd.ref1 = ref, nd._pad0 = nd._pad1 = 0;
+        nodes.push_back(nd);
+        return 1;
+    }
+    return B.levels;
 }

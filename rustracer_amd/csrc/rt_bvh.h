@@ -11,4 +11,5 @@
 // scenes with more bounded primitives than this get a BVH (below it the scalar-load linear scan wins)
 #define RT_BVH_THRESHOLD 64ull
 
-void rt_build_bvh(const rthip_scene_desc *scene, std::vector<DevBvhNode> &nodes, std::vector<uint32_t> &prims);
+// returns the number of traversal stack levels the tree needs (<= RT_BVH_MAX_DEPTH), 0 for an empty scene
+uint32_t rt_build_bvh(const rthip_scene_desc *scene, std::vector<DevBvhNode> &nodes, std::vector<uint32_t> &prims);

@@ -11,11 +11,12 @@
 //   materials [n_mat]     3 x float4, see DevMaterial
 //   texels    RGBA8, one u32 per texel, 8x8-texel tiles (64 consecutive u32 = 256 B per tile)
 //   tex_info  [n_tex]     {width, height, tiles_per_row, first_texel}
-//   bvh nodes [n_nodes]   32 B each, see DevBvhNode (2 per 64-B line)
+//   bvh_nodes [n_nodes]   64 B each (both child boxes), bvh_recs [n_prims] 3 x float4 in leaf order, see DevBvhNode
 #pragma once
 #include <stdint.h>
 
 #define RT_LDS_SPHERES 256u
+#define RT_CHUNK_BVH 8u
 #define RT_T_MIN 0.001f      /* raytracer_core/src/shapes/ray.rs:5 */
 #define RT_T_MAX 100000.0f   /* raytracer_core/src/shapes/ray.rs:6 */
 
@@ -41,18 +42,29 @@ struct DevTexInfo {
 
 struct DevLight { float px, py, pz, _p0, ir, ig, ib, _p1; };
 
-// Linear BVH node, 32 B. Leaf iff (count & RT_BVH_COUNT_MASK) > 0: prims [first, first+count) of the
-// BVH-ordered primitive index array; inner: left child = node index + 1 (depth-first layout),
-// right child = `first`, split axis in the top two bits of `count` (near child first).
+// BVH node, 64 B = one cache line = 4 x float4: the boxes of BOTH children and a reference to each,
+// so that one fetch decides both descents (half the dependent loads of a box-per-node layout).
+// A reference is an inner node index (< RT_BVH_DONE; the root is node 0) or, with RT_BVH_LEAF_BIT
+// set, a leaf: (first << 2) | (count - 1), primitives [first, first + count) of the BVH-ordered
+// record array bvh_recs (count <= RT_BVH_LEAF, first < 2^29).
+// bvh_recs: 3 x float4 per primitive, in leaf order (no index indirection):
+//   triangle {v0, global shape index} {e1, kind = 1} {e2, 0};  sphere {c, global shape index} {r*r, 0, 0, kind = 0} {0}
 #define RT_BVH_LEAF 4u
+#ifndef RT_BVH_MAX_DEPTH
 #define RT_BVH_MAX_DEPTH 32
-#define RT_BVH_COUNT_MASK 0x3fffffffu
-#define RT_BVH_AXIS_SHIFT 30
+#endif
+#define RT_BVH_LEAF_BIT 0x80000000u
+#define RT_BVH_DONE 0x7fffffffu
+#define RT_BVH_MAX_PRIMS (1ull << 29)
 struct DevBvhNode {
-    float lo[3];
-    uint32_t first;
-    float hi[3];
-    uint32_t count;
+    float lo0[3];
+    uint32_t ref0;
+    float hi0[3];
+    uint32_t ref1;
+    float lo1[3];
+    uint32_t _pad0;
+    float hi1[3];
+    uint32_t _pad1;
 };
 
 struct KernelParams {
@@ -69,7 +81,8 @@ struct KernelParams {
     uint32_t accumulate;  // add the prior running sum (lib.rs:289-291)
     // scene
     uint32_t n_spheres, n_planes, n_tris, n_lights, n_bvh_nodes;
-    uint32_t n_bvh_spheres;  // BVH prim ids < n_bvh_spheres are spheres, the rest triangles (id - n_bvh_spheres)
+    uint32_t bvh_levels;  // traversal stack levels = depth of the tree
+    uint32_t chunk;       // samples per chunk of the per-wave work pool (set by rt_launch_render)
     const rt_f4 *sph_geom;
     const rt_f4 *sph_shade;
     const rt_f4 *pln_geom;
@@ -79,7 +92,7 @@ struct KernelParams {
     const DevTexInfo *tex_info;
     const DevLight *lights;
     const DevBvhNode *bvh_nodes;
-    const uint32_t *bvh_prims;
+    const rt_f4 *bvh_recs;
     // outputs
     float *accum;        // context-owned running sum, owned_rows*width*3
     float *accum_out;    // optional caller copy (may be null)

@@ -21,6 +21,8 @@
 // No MFMA: there is no dense contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/rthip.h"
 #include "rt_device.h"
 #include "rt_rng.h"
@@ -129,70 +131,135 @@ __device__ __forceinline__ bool hit_tri(rt_f4 v0, rt_f4 e1_, rt_f4 e2_, const Ra
         __VA_ARGS__;                                                                             \
     }
 
-// ---- linear BVH traversal (extension; big scenes) --------------------------------------------
-// Per-lane stack in LDS ([level][thread]: conflict-free), near child first by the split axis.
-// A node is entered iff the ray's slab interval overlaps (tmin, min(best t, tmax)] — INCLUSIVE of
+// ---- BVH traversal (extension; big scenes) ----------------------------------------------------
+// "while-while" traversal (Aila & Laine 2009): every lane first walks inner nodes until it holds a
+// leaf (or is done), then the wave intersects leaves together, so that box tests and primitive
+// tests do not serialise against each other inside a wave. One 64-byte node fetch (4 independent
+// 16-byte loads) tests both children; the nearer child is entered first, the farther one is pushed
+// on the per-lane stack in LDS ([level][thread]: conflict-free).
+// A child is entered iff the ray's slab interval overlaps (tmin, min(best t, tmax)] — INCLUSIVE of
 // the current best t, so that an equal-t shape with a larger index is still found (ray.rs:55-61).
+// Slab planes are evaluated as fma(plane, 1/d, -o/d): against (plane - o)/d that moves a plane by
+// about one ulp of its coordinate, which the builder's box padding (rt_bvh.cpp) covers many times
+// over; a zero direction component gives NaN on that axis, which v_min/v_max drop (conservative).
 #define RT_STACK_AT(level) s_stack[(level) * 256 + threadIdx.x]
 
-template <bool STATS, bool ANY>
-__device__ __forceinline__ bool bvh_traverse(const KernelParams &P, const Ray &r, uint32_t self, HitRec &h, uint32_t *cnt, uint32_t *s_stack) {
-    const f3 inv_d = mk3(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
-    const uint32_t tri_base = P.n_spheres + P.n_planes;
-    int sp = 0;
-    uint32_t node = 0;
+__device__ __forceinline__ bool slab_test(rt_f4 lo, rt_f4 hi, f3 inv_d, f3 noi, float tmin, float limit, float &tn_out) {
+    const float ax = fmaf(lo.x, inv_d.x, noi.x), bx = fmaf(hi.x, inv_d.x, noi.x);
+    const float ay = fmaf(lo.y, inv_d.y, noi.y), by = fmaf(hi.y, inv_d.y, noi.y);
+    const float az = fmaf(lo.z, inv_d.z, noi.z), bz = fmaf(hi.z, inv_d.z, noi.z);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
+    tn_out = tn;
+    return tn <= tf && tn <= limit && tf >= tmin;
+}
+
+// Traversal state of one lane; it survives across calls of bvh_run so that a lane whose ray is
+// still inside the tree can be parked while the finished lanes of its wave shade and fetch new rays.
+struct BvhState {
+    f3 inv_d, noi;  // 1/d and -o/d
+    uint32_t ref;   // node/leaf reference in flight, RT_BVH_DONE when the ray has left the tree
+    int sp;
+};
+__device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
+    s.inv_d = mk3(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
+    s.noi = mk3(-r.o.x * s.inv_d.x, -r.o.y * s.inv_d.y, -r.o.z * s.inv_d.z);
+    s.ref = 0;  // the root is always an inner node
+    s.sp = 0;
+}
+#ifndef RT_BVH_YIELD_LANES
+#define RT_BVH_YIELD_LANES 16
+#endif
+// Runs the traversal of every calling lane. YIELD: returns early (s.ref != RT_BVH_DONE on the
+// unfinished lanes) once RT_BVH_YIELD_LANES lanes of the wave have finished, so that the caller can
+// give them new rays instead of idling them until the slowest ray of the wave is done (ray
+// lengths in the tree are heavy-tailed: without this a wave runs at ~20 % lane utilisation).
+// ANY: any-hit query, returns true on the first hit inside the window.
+template <bool STATS, bool ANY, bool YIELD>
+__device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uint32_t self, HitRec &h, BvhState &s, uint32_t *cnt, uint32_t *s_stack) {
+    const rt_f4 *nodes = (const rt_f4 *)P.bvh_nodes;
+    uint32_t ref = s.ref;
+    int sp = s.sp;
+    bool found = false;
     for (;;) {
-        const rt_f4 n0 = ((const rt_f4 *)P.bvh_nodes)[2 * node], n1 = ((const rt_f4 *)P.bvh_nodes)[2 * node + 1];
-        if (STATS) cnt[RT_STAT_NODE]++;
-        const float ax = (n0.x - r.o.x) * inv_d.x, bx = (n1.x - r.o.x) * inv_d.x;
-        const float ay = (n0.y - r.o.y) * inv_d.y, by = (n1.y - r.o.y) * inv_d.y;
-        const float az = (n0.z - r.o.z) * inv_d.z, bz = (n1.z - r.o.z) * inv_d.z;
-        const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
-        const float limit = ANY ? r.tmax : fminf(h.t, r.tmax);
-        if (tn <= tf && tn <= limit && tf >= r.tmin) {
-            const uint32_t first = __float_as_uint(n0.w), cw = __float_as_uint(n1.w);
-            const uint32_t count = cw & RT_BVH_COUNT_MASK;
-            if (count) {
-                for (uint32_t k = 0; k < count; k++) {
-                    const uint32_t id = P.bvh_prims[first + k];
-                    if (id < P.n_bvh_spheres) {
-                        float t;
-                        bool ok = hit_sphere(P.sph_geom[id], r, id == self, t);
-                        if (STATS) cnt[RT_STAT_SPHERE]++;
-                        if (ANY) {
-                            if (ok) return true;
-                        } else {
-                            RT_TAKE_ANY_ORDER(ok, t, id, (void)0)
-                        }
-                    } else {
-                        const uint32_t ti = id - P.n_bvh_spheres;
-                        float t, b1, b2;
-                        bool ok = hit_tri(P.tri_geom[3 * ti], P.tri_geom[3 * ti + 1], P.tri_geom[3 * ti + 2], r, t, b1, b2);
-                        if (STATS) cnt[RT_STAT_TRI]++;
-                        if (ANY) {
-                            if (ok) return true;
-                        } else {
-                            RT_TAKE_ANY_ORDER(ok, t, tri_base + ti, (h.b1 = b1, h.b2 = b2))
-                        }
-                    }
-                }
-            } else {
-                const uint32_t axis = cw >> RT_BVH_AXIS_SHIFT;
-                const float da = axis == 0 ? r.d.x : (axis == 1 ? r.d.y : r.d.z);
-                const uint32_t left = node + 1, right = first;
-                const bool right_first = da < 0.0f;
-                RT_STACK_AT(sp) = right_first ? left : right;
+        while (ref < RT_BVH_DONE) {  // inner node
+            const rt_f4 q0 = nodes[4 * ref], q1 = nodes[4 * ref + 1], q2 = nodes[4 * ref + 2], q3 = nodes[4 * ref + 3];
+            if (STATS) cnt[RT_STAT_NODE] += 2;
+            const float limit = ANY ? r.tmax : fminf(h.t, r.tmax);
+            float tn0, tn1;
+            const bool h0 = slab_test(q0, q1, s.inv_d, s.noi, r.tmin, limit, tn0);
+            const bool h1 = slab_test(q2, q3, s.inv_d, s.noi, r.tmin, limit, tn1);
+            const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
+            if (h0 & h1) {
+                const bool second_first = tn1 < tn0;
+                RT_STACK_AT(sp) = second_first ? r0 : r1;
                 sp++;
-                node = right_first ? right : left;
-                continue;
+                ref = second_first ? r1 : r0;
+            } else if (h0 | h1) {
+                ref = h0 ? r0 : r1;
+            } else if (sp > 0) {
+                sp--;
+                ref = RT_STACK_AT(sp);
+            } else {
+                ref = RT_BVH_DONE;
             }
         }
-        if (sp == 0) break;
-        sp--;
-        node = RT_STACK_AT(sp);
+        if (ref != RT_BVH_DONE) {  // leaf
+            const uint32_t first = (ref & ~RT_BVH_LEAF_BIT) >> 2, count = (ref & 3u) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                const rt_f4 *rec = P.bvh_recs + 3 * size_t(first + k);
+                const rt_f4 a = rec[0], b = rec[1], c = rec[2];
+                const uint32_t id = __float_as_uint(a.w);
+                if (__float_as_uint(b.w) == 0u) {
+                    float t;
+                    bool ok = hit_sphere(rt_f4{a.x, a.y, a.z, b.x}, r, id == self, t);
+                    if (STATS) cnt[RT_STAT_SPHERE]++;
+                    if (ANY) {
+                        found |= ok;
+                    } else {
+                        RT_TAKE_ANY_ORDER(ok, t, id, (void)0)
+                    }
+                } else {
+                    float t, b1, b2;
+                    bool ok = hit_tri(a, b, c, r, t, b1, b2);
+                    if (STATS) cnt[RT_STAT_TRI]++;
+                    if (ANY) {
+                        found |= ok;
+                    } else {
+                        RT_TAKE_ANY_ORDER(ok, t, id, (h.b1 = b1, h.b2 = b2))
+                    }
+                }
+            }
+            if (sp > 0 && !(ANY && found)) {
+                sp--;
+                ref = RT_STACK_AT(sp);
+            } else {
+                ref = RT_BVH_DONE;
+            }
+        }
+        const unsigned long long finished = __ballot(ref == RT_BVH_DONE), here = __ballot(true);
+        if (finished == here) break;
+        if (YIELD && __popcll(finished) >= RT_BVH_YIELD_LANES) break;
     }
-    return false;
+    s.ref = ref;
+    s.sp = sp;
+    return found;
+}
+
+// MODE_BVH, first half of the closest-hit query: the shapes outside the tree (planes are unbounded)
+template <bool STATS>
+__device__ __forceinline__ HitRec closest_hit_unbounded(const KernelParams &P, const Ray &r, uint32_t *cnt) {
+    HitRec h;
+    h.t = __uint_as_float(__float_as_uint(r.tmax) - 1u);  // largest float below tmax (tmax > 0)
+    h.shape = RT_NONE;
+    h.b1 = h.b2 = 0.0f;
+    for (uint32_t i = 0; i < P.n_planes; i++) {
+        float t;
+        bool ok = hit_plane(P.pln_geom[4 * i], r, t);
+        RT_TAKE(ok, t, P.n_spheres + i, (void)0)
+    }
+    if (STATS) cnt[RT_STAT_PLANE] += P.n_planes;
+    return h;
 }
 
 template <bool STATS, int MODE>
@@ -239,7 +306,9 @@ __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &
             cnt[RT_STAT_TRI] += P.n_tris;
         }
     } else {
-        bvh_traverse<STATS, false>(P, r, self, h, cnt, s_stack);
+        BvhState bs;
+        bvh_begin(r, bs);
+        bvh_run<STATS, false, false>(P, r, self, h, bs, cnt, s_stack);
     }
     if (STATS) cnt[RT_STAT_PLANE] += P.n_planes;
     return h;
@@ -269,7 +338,9 @@ __device__ __forceinline__ bool occluded(const KernelParams &P, const Ray &r, ui
         HitRec dummy;
         dummy.t = r.tmax;
         dummy.shape = RT_NONE;
-        occ = bvh_traverse<STATS, true>(P, r, self, dummy, cnt, s_stack);
+        BvhState bs;
+        bvh_begin(r, bs);
+        occ = bvh_run<STATS, true, false>(P, r, self, dummy, bs, cnt, s_stack);
     }
     return occ;
 }
@@ -304,13 +375,33 @@ struct Surface {
     float tu, tv, tw;  // sphere: (p-c).z, (p-c).x, (p-c).y/r for the texture coordinates (sphere.rs:67-73)
 };
 
-// One full pass over a pixel: generate_pixel (lib.rs:269-316) with project_ray (ray.rs:42-87) inlined.
+// One full pass over the frame: generate_pixel (lib.rs:269-316) with project_ray (ray.rs:42-87) inlined.
+//
+// Work distribution inside a wave (a wave owns an 8x8 pixel tile).
+//  * Scan modes (MODE_LDS, MODE_GLOBAL): lane = pixel; a lane whose path ended starts its pixel's next
+//    sample at once (path regeneration), so lanes only idle at the very end of a tile.
+//  * MODE_BVH (POOL): per-ray cost in a tree is heavy-tailed and differs a lot between the pixels of a
+//    tile (sky vs. mesh silhouette): with lane = pixel 80 % of the lanes idle. So a lane does NOT own
+//    a pixel while tracing: the tile's (pixel, sample) pairs of a chunk of `P.chunk` samples form a
+//    pool of 64*chunk work items, item i = (pixel i & 63, sample i >> 6), and a lane whose path has
+//    ended takes the next item of the pool (ballot + prefix count, no atomics). Each finished item
+//    stores its radiance in its own LDS slot; at the end of a chunk lane p adds the slots of pixel p
+//    in sample order, so the sum is exactly that of the sequential loop of lib.rs:281-288 and
+//    independent of which lane traced what. (Measured: the pool costs the scan modes 9 % — their
+//    idle lanes come from divergent shading branches, not from unequal pixels — hence not used there.)
+//
+// Dynamic LDS layout (bytes): [MODE_LDS: RT_LDS_SPHERES x 16 geometry | 3 x n_spheres x 16 shading]
+// [MODE_BVH: bvh_levels x 256 x 4 traversal stack | 4 waves x 64 x 16 per-pixel {base direction, RNG key}
+// | 4 waves x 3 x 64*chunk x 4 radiance slots]; rt_launch_render computes the size.
 template <bool STATS, int MODE, bool LIGHTS>
 __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
-    __shared__ uint32_t s_stack_mem[MODE == MODE_BVH ? RT_BVH_MAX_DEPTH * 256 : 1];
-    __shared__ rt_f4 s_geom_mem[MODE == MODE_LDS ? RT_LDS_SPHERES : 1];
-    __shared__ rt_f4 s_shade_mem[MODE == MODE_LDS ? 3 * RT_LDS_SPHERES : 1];
-    uint32_t *s_stack = s_stack_mem;
+    constexpr bool POOL = MODE == MODE_BVH;
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    rt_f4 *s_geom_mem = (rt_f4 *)s_dyn;
+    rt_f4 *s_shade_mem = s_geom_mem + (MODE == MODE_LDS ? RT_LDS_SPHERES : 0u);  // fixed offsets: folded into the ds_read offset field
+    uint32_t *s_stack = (uint32_t *)(s_shade_mem + (MODE == MODE_LDS ? 3u * P.n_spheres : 0u));
+    rt_f4 *s_pix_all = (rt_f4 *)(s_stack + (MODE == MODE_BVH ? P.bvh_levels * 256u : 0u));
+    float *s_L_all = (float *)(s_pix_all + 256);
     const rt_f4 *s_geom = s_geom_mem;
     if (MODE == MODE_LDS) {
         for (uint32_t i = threadIdx.x; i < P.n_spheres; i += 256) s_geom_mem[i] = P.sph_geom[i];
@@ -329,26 +420,39 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
         y = (P.band_first + k * P.band_stride) * P.band_rows + (lrow - k * P.band_rows);
     }
     const bool active = x < P.width && lrow < P.owned_rows && y < P.height;
+    const unsigned long long amask = __ballot(active);  // pixels of this wave's tile that exist
 
     uint32_t cnt[RT_STAT_N];
 #pragma unroll
     for (int i = 0; i < RT_STAT_N; i++) cnt[i] = 0;
 
-    if (active) {
-        const uint32_t pixel_index = y * P.width + x;
-        const uint32_t pkey = rt_pixel_key(rt_seed_key(P.seed), pixel_index);
+    if (amask != 0ull) {
+        rt_f4 *s_pix = s_pix_all + (wave << 6);
+        const uint32_t plane = P.chunk << 6;  // floats per colour plane of the wave's radiance slots
+        float *s_L = s_L_all + wave * 3u * plane;
+        rt_f4 pp_own;
+        {
+            // per pixel: direction through its lower-left corner d00 + H*x/(W-1) + V*y/(H-1) (camera.rs:46-48,
+            // lib.rs:282-285) and its RNG key
+            const float pu = float(x) * P.inv_wm1, pv = float(y) * P.inv_hm1;
+            rt_f4 pp;
+            pp.x = fmaf(P.vx, pv, fmaf(P.hx, pu, P.d00x));
+            pp.y = fmaf(P.vy, pv, fmaf(P.hy, pu, P.d00y));
+            pp.z = fmaf(P.vz, pv, fmaf(P.hz, pu, P.d00z));
+            pp.w = __uint_as_float(rt_pixel_key(rt_seed_key(P.seed), y * P.width + x));
+            if (POOL) s_pix[lane] = pp;
+            pp_own = pp;
+        }
         const f3 cam_o = mk3(P.ox, P.oy, P.oz);
-        // direction through the pixel's lower-left corner: d00 + H*x/(W-1) + V*y/(H-1)   (camera.rs:46-48, lib.rs:282-285)
-        const float pu = float(x) * P.inv_wm1, pv = float(y) * P.inv_hm1;
-        const f3 pix_d = mk3(fmaf(P.vx, pv, fmaf(P.hx, pu, P.d00x)), fmaf(P.vy, pv, fmaf(P.hy, pu, P.d00y)), fmaf(P.vz, pv, fmaf(P.hz, pu, P.d00z)));
         f3 acc = mk3(0.0f, 0.0f, 0.0f);
-        uint32_t s = 0;
-        uint32_t key0 = rt_counter(pkey, P.sample0, 0);  // RNG counter of the current path's slot 0
-        uint32_t key = key0;                             // ... and of the slot in use (advances by GOLDEN per segment)
-        uint32_t bounce;
-        uint32_t self;  // shape the current ray starts on
+        // ---- state of the path this lane is tracing ----
+        uint32_t item = 0;   // slot of the work item in the chunk
+        uint32_t key = 0;    // RNG counter of the slot in use (advances by GOLDEN per segment)
+        uint32_t bounce = 0;
+        uint32_t self = RT_NONE;  // shape the current ray starts on
         Ray r;
-        f3 T;
+        r.o = cam_o, r.d = mk3(0.0f, 0.0f, -1.0f), r.tmin = r.tmax = 0.0f;
+        f3 T = mk3(1.0f, 1.0f, 1.0f);
         f3 Ld = mk3(0.0f, 0.0f, 0.0f);  // extension: direct light gathered along the path (point-light mode)
         // Ray::new with an un-normalised direction: keep the unit vector, fold |d| into the window
         auto set_dir = [&](f3 nd) {
@@ -359,29 +463,59 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
             r.tmin = RT_T_MIN * len;
             r.tmax = RT_T_MAX * len;
         };
-        auto new_path = [&]() {
+        uint32_t key_own = rt_counter(__float_as_uint(pp_own.w), P.sample0, 0);  // !POOL: slot 0 of this pixel's next sample
+        auto new_path = [&](uint32_t pixel, uint32_t sample) {
+            rt_f4 pp;
+            if (POOL) {
+                pp = s_pix[pixel];
+                key = rt_counter(__float_as_uint(pp.w), sample, 0);
+            } else {
+                pp = pp_own;
+                key = key_own;
+                key_own += RT_RNG_SLOTS * RT_RNG_GOLDEN;
+            }
             // lib.rs:282-285: x jitter first
-            const uint32_t hj = rt_mix32(key0);
-            key = key0;
-            // u = (x + xi)/(W-1) = x/(W-1) + xi/(W-1): the per-pixel part is loop-invariant (pix_d)
+            const uint32_t hj = rt_mix32(key);
+            // u = (x + xi)/(W-1) = x/(W-1) + xi/(W-1): the per-pixel part is precomputed (s_pix)
             const float ju = rt_unit(hj) * P.inv_wm1;
             const float jv = rt_unit(rt_second(hj)) * P.inv_hm1;
             r.o = cam_o;  // camera.rs:43-50
-            set_dir(mk3(fmaf(P.vx, jv, fmaf(P.hx, ju, pix_d.x)), fmaf(P.vy, jv, fmaf(P.hy, ju, pix_d.y)), fmaf(P.vz, jv, fmaf(P.hz, ju, pix_d.z))));
+            set_dir(mk3(fmaf(P.vx, jv, fmaf(P.hx, ju, pp.x)), fmaf(P.vy, jv, fmaf(P.hy, ju, pp.y)), fmaf(P.vz, jv, fmaf(P.hz, ju, pp.z))));
             T = mk3(1.0f, 1.0f, 1.0f);
             bounce = 0;
             self = RT_NONE;
             if (LIGHTS) Ld = mk3(0.0f, 0.0f, 0.0f);
         };
-        new_path();
-        for (;;) {
-            f3 L;
+        HitRec h;
+        h.t = 0.0f, h.shape = RT_NONE, h.b1 = h.b2 = 0.0f;
+        BvhState bs;           // MODE_BVH: the closest-hit query is resumable
+        bs.ref = RT_BVH_DONE, bs.sp = 0, bs.inv_d = bs.noi = mk3(0.0f, 0.0f, 0.0f);
+        bool tracing = false;  // ... and this lane's ray is still inside the tree
+        // One segment of the lane's path: closest hit, shading, next ray. Returns 0 = the path goes on,
+        // 1 = the path ended with radiance L, 2 (MODE_BVH) = the ray is parked inside the tree.
+        auto segment = [&](f3 &L) -> int {
             bool done;
-            HitRec h;
-            h.shape = RT_NONE;
-            if (bounce != P.max_depth) {  // ray.rs:70-72: depth exhausted -> sky without a scene query
-                h = closest_hit<STATS, MODE>(P, r, self, cnt, s_stack, s_geom);
-                cnt[RT_STAT_RAYS]++;
+            if (MODE == MODE_BVH) {
+                if (!tracing) {
+                    h.shape = RT_NONE;
+                    if (bounce != P.max_depth) {  // ray.rs:70-72: depth exhausted -> sky without a scene query
+                        h = closest_hit_unbounded<STATS>(P, r, cnt);
+                        bvh_begin(r, bs);
+                        tracing = true;
+                        cnt[RT_STAT_RAYS]++;
+                    }
+                }
+                if (tracing) {
+                    bvh_run<STATS, false, true>(P, r, self, h, bs, cnt, s_stack);
+                    if (bs.ref != RT_BVH_DONE) return 2;  // parked: the finished lanes of the wave shade and fetch new work
+                    tracing = false;
+                }
+            } else {
+                h.shape = RT_NONE;
+                if (bounce != P.max_depth) {  // ray.rs:70-72: depth exhausted -> sky without a scene query
+                    h = closest_hit<STATS, MODE>(P, r, self, cnt, s_stack, s_geom);
+                    cnt[RT_STAT_RAYS]++;
+                }
             }
             if (h.shape == RT_NONE) {  // ray.rs:85, background_color ray.rs:89-93 (the direction is already unit)
                 const float t = fmaf(0.5f, r.d.y, 0.5f);
@@ -394,8 +528,17 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                 // ---- the surface: normal + material (collision.rs:29-43) ----
                 Surface sf;
                 if (h.shape < P.n_spheres) {
-                    const rt_f4 *rec = (MODE == MODE_LDS) ? (s_shade_mem + 3 * h.shape) : (P.sph_shade + 3 * h.shape);
-                    const rt_f4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    rt_f4 r0, r1, r2;
+                    if constexpr (MODE == MODE_LDS) {  // kept apart so that the LDS reads stay ds_read_b128 (no generic pointer)
+                        const rt_f4 *rec = s_shade_mem + 3 * h.shape;
+                        r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                        // pin the loaded values: otherwise the loads are sunk to their uses and merged with the
+                        // material loads of the non-sphere branch into per-dword flat loads
+                        asm volatile("" : "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w), "+v"(r2.x), "+v"(r2.y), "+v"(r2.z), "+v"(r2.w));
+                    } else {
+                        const rt_f4 *rec = P.sph_shade + 3 * h.shape;
+                        r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    }
                     const f3 pc = mk3(p.x - r0.x, p.y - r0.y, p.z - r0.z);
                     sf.n = pc * r0.w;  // (p - c)/r
                     sf.tm = mk3(r1.x, r1.y, r1.z);
@@ -520,37 +663,90 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                     bounce++;
                 }
             }
-            if (done) {
-                if (LIGHTS) L = L + Ld;
-                acc = acc + L;  // lib.rs:287
-                cnt[RT_STAT_PATHS]++;
-                s++;
-                if (s == P.spp) break;
-                key0 += RT_RNG_SLOTS * RT_RNG_GOLDEN;
-                new_path();
+            if (done && LIGHTS) L = L + Ld;
+            return done ? 1 : 0;
+        };
+        if constexpr (!POOL) {
+            // ---- lane = pixel: path regeneration over the pixel's samples ----
+            if (active) {
+                uint32_t s_left = P.spp;
+                new_path(lane, 0);
+                for (;;) {
+                    f3 L;
+                    if (segment(L)) {
+                        acc = acc + L;  // lib.rs:287
+                        cnt[RT_STAT_PATHS]++;
+                        if (--s_left == 0) break;
+                        new_path(lane, 0);
+                    }
+                }
+            }
+        } else {
+            for (uint32_t s_base = 0; s_base < P.spp; s_base += P.chunk) {
+                const uint32_t total = min(P.chunk, P.spp - s_base) << 6;  // work items of this chunk
+                uint32_t next = 0;                                          // first item not yet handed out (wave-uniform)
+                bool have = false;                                          // this lane is tracing a path
+                for (;;) {
+                    // ---- idle lanes take the next items of the pool, in lane order ----
+                    const unsigned long long need = __ballot(!have);
+                    if (!have) {
+                        const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi(uint32_t(need >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(need), 0u));
+                        if (idx < total && ((amask >> (idx & 63u)) & 1ull)) {
+                            item = idx;
+                            have = true;
+                            new_path(idx & 63u, P.sample0 + s_base + (idx >> 6));
+                        }
+                    }
+                    next = min(next + uint32_t(__popcll(need)), total);
+                    if (__ballot(have) == 0ull) break;
+                    if (have) {
+                        f3 L;
+                        if (segment(L) == 1) {
+                            s_L[item] = L.x;  // lib.rs:287, summed in sample order below
+                            s_L[plane + item] = L.y;
+                            s_L[2u * plane + item] = L.z;
+                            cnt[RT_STAT_PATHS]++;
+                            have = false;
+                        }
+                    }
+                }
+                // ---- lane p adds the samples of pixel p, in sample order ----
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (active) {
+                    for (uint32_t k = lane; k < total; k += 64u) {
+                        acc.x += s_L[k];
+                        acc.y += s_L[plane + k];
+                        acc.z += s_L[2u * plane + k];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        // lib.rs:289-299: add the prior running sum, store it, tonemap
-        const size_t oi = size_t(lrow) * P.width + x;
-        if (P.accumulate) {
-            acc.x += P.accum[oi * 3 + 0];
-            acc.y += P.accum[oi * 3 + 1];
-            acc.z += P.accum[oi * 3 + 2];
-        }
-        P.accum[oi * 3 + 0] = acc.x;
-        P.accum[oi * 3 + 1] = acc.y;
-        P.accum[oi * 3 + 2] = acc.z;
-        if (P.accum_out) {
-            P.accum_out[oi * 3 + 0] = acc.x;
-            P.accum_out[oi * 3 + 1] = acc.y;
-            P.accum_out[oi * 3 + 2] = acc.z;
-        }
-        if (P.rgba8) {
-            // mean, clamp(0,1), sqrt, *255, `as u8` (truncate, saturate, NaN -> 0): lib.rs:294-299,30-38
-            float cr = __fsqrt_rn(fminf(fmaxf(acc.x * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
-            float cg = __fsqrt_rn(fminf(fmaxf(acc.y * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
-            float cb = __fsqrt_rn(fminf(fmaxf(acc.z * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
-            P.rgba8[oi] = uint32_t(cr) | (uint32_t(cg) << 8) | (uint32_t(cb) << 16) | 0xff000000u;
+        if (active) {
+            // lib.rs:289-299: add the prior running sum, store it, tonemap
+            const size_t oi = size_t(lrow) * P.width + x;
+            if (P.accumulate) {
+                acc.x += P.accum[oi * 3 + 0];
+                acc.y += P.accum[oi * 3 + 1];
+                acc.z += P.accum[oi * 3 + 2];
+            }
+            P.accum[oi * 3 + 0] = acc.x;
+            P.accum[oi * 3 + 1] = acc.y;
+            P.accum[oi * 3 + 2] = acc.z;
+            if (P.accum_out) {
+                P.accum_out[oi * 3 + 0] = acc.x;
+                P.accum_out[oi * 3 + 1] = acc.y;
+                P.accum_out[oi * 3 + 2] = acc.z;
+            }
+            if (P.rgba8) {
+                // mean, clamp(0,1), sqrt, *255, `as u8` (truncate, saturate, NaN -> 0): lib.rs:294-299,30-38
+                float cr = __fsqrt_rn(fminf(fmaxf(acc.x * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
+                float cg = __fsqrt_rn(fminf(fmaxf(acc.y * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
+                float cb = __fsqrt_rn(fminf(fmaxf(acc.z * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
+                P.rgba8[oi] = uint32_t(cr) | (uint32_t(cg) << 8) | (uint32_t(cb) << 16) | 0xff000000u;
+            }
         }
     }
 
@@ -583,28 +779,51 @@ __global__ void pick_kernel(const KernelParams P, float u, float v, long long *o
 
 // ---- launch wrappers (called from rthip_api.cpp) -----------------------------------------
 template <bool STATS, int MODE>
-static void launch_variant(const KernelParams &P, bool lights, uint32_t blocks, hipStream_t stream) {
+static void launch_variant(const KernelParams &P, bool lights, uint32_t blocks, uint32_t lds, hipStream_t stream) {
     if (lights)
-        hipLaunchKernelGGL((render_kernel<STATS, MODE, true>), dim3(blocks), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((render_kernel<STATS, MODE, true>), dim3(blocks), dim3(256), lds, stream, P);
     else
-        hipLaunchKernelGGL((render_kernel<STATS, MODE, false>), dim3(blocks), dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((render_kernel<STATS, MODE, false>), dim3(blocks), dim3(256), lds, stream, P);
 }
 
 template <bool STATS>
-static void launch_mode(const KernelParams &P, int mode, bool lights, uint32_t blocks, hipStream_t stream) {
-    if (mode == MODE_BVH) launch_variant<STATS, MODE_BVH>(P, lights, blocks, stream);
-    else if (mode == MODE_LDS) launch_variant<STATS, MODE_LDS>(P, lights, blocks, stream);
-    else launch_variant<STATS, MODE_GLOBAL>(P, lights, blocks, stream);
+static void launch_mode(const KernelParams &P, int mode, bool lights, uint32_t blocks, uint32_t lds, hipStream_t stream) {
+    if (mode == MODE_BVH) launch_variant<STATS, MODE_BVH>(P, lights, blocks, lds, stream);
+    else if (mode == MODE_LDS) launch_variant<STATS, MODE_LDS>(P, lights, blocks, lds, stream);
+    else launch_variant<STATS, MODE_GLOBAL>(P, lights, blocks, lds, stream);
 }
 
-extern "C" hipError_t rt_launch_render(const KernelParams *P, int count_stats, hipStream_t stream) {
-    const uint32_t tiles_x = (P->width + 15u) >> 4, tiles_y = (P->owned_rows + 15u) >> 4;
+// MODE_BVH: samples per chunk of the per-wave work pool (the radiance slots cost 768 B of LDS per sample and wave)
+static uint32_t default_chunk() {
+    static const int env = [] {
+        const char *e = getenv("RTHIP_CHUNK");  // tuning knob; results do not depend on it
+        return e ? atoi(e) : 0;
+    }();
+    if (env > 0) return uint32_t(env > 16 ? 16 : env);
+    return RT_CHUNK_BVH;
+}
+
+extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats, hipStream_t stream) {
+    KernelParams P = *Pin;
+    const uint32_t tiles_x = (P.width + 15u) >> 4, tiles_y = (P.owned_rows + 15u) >> 4;
     const uint32_t blocks = tiles_x * tiles_y;
-    if (blocks == 0) return hipSuccess;
-    const bool lights = (P->flags & RTHIP_F_POINT_LIGHTS) && P->n_lights > 0;
-    const int mode = P->n_bvh_nodes > 0 ? MODE_BVH : (P->n_spheres <= RT_LDS_SPHERES ? MODE_LDS : MODE_GLOBAL);
-    if (count_stats) launch_mode<true>(*P, mode, lights, blocks, stream);
-    else launch_mode<false>(*P, mode, lights, blocks, stream);
+    if (blocks == 0 || P.spp == 0) return hipSuccess;
+    const bool lights = (P.flags & RTHIP_F_POINT_LIGHTS) && P.n_lights > 0;
+    const int mode = P.n_bvh_nodes > 0 ? MODE_BVH : (P.n_spheres <= RT_LDS_SPHERES ? MODE_LDS : MODE_GLOBAL);
+    uint32_t lds = 0;
+    if (mode == MODE_BVH) {
+        if (P.bvh_levels == 0 || P.bvh_levels > RT_BVH_MAX_DEPTH) return hipErrorInvalidValue;
+        P.chunk = default_chunk();
+        if (P.chunk > P.spp) P.chunk = P.spp;
+        lds = P.bvh_levels * 1024u + 4096u + 4u * 3u * 64u * 4u * P.chunk;
+    } else {
+        P.chunk = P.spp;  // lane = pixel: one "chunk", no radiance slots
+        P.bvh_levels = 0;
+        lds = (mode == MODE_LDS) ? (RT_LDS_SPHERES + 3u * P.n_spheres) * 16u : 16u;
+    }
+    if (lds > 65536u) return hipErrorInvalidValue;
+    if (count_stats) launch_mode<true>(P, mode, lights, blocks, lds, stream);
+    else launch_mode<false>(P, mode, lights, blocks, lds, stream);
     return hipGetLastError();
 }
 

@@ -35,7 +35,7 @@ struct DevBuf {
 struct rthip_ctx {
     int device = 0;
     std::string err;
-    DevBuf sph_geom, sph_shade, pln_geom, tri_geom, materials, texels, tex_info, lights, bvh_nodes, bvh_prims;
+    DevBuf sph_geom, sph_shade, pln_geom, tri_geom, materials, texels, tex_info, lights, bvh_nodes, bvh_recs;
     DevBuf stats, accum, staging_rgba, staging_accum, pick_out;
     KernelParams base;
     bool have_scene = false, have_camera = false;
@@ -247,7 +247,7 @@ void rthip_destroy(rthip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->sph_geom, &ctx->sph_shade, &ctx->pln_geom, &ctx->tri_geom, &ctx->materials, &ctx->texels, &ctx->tex_info, &ctx->lights,
-                      &ctx->bvh_nodes, &ctx->bvh_prims, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out})
+                      &ctx->bvh_nodes, &ctx->bvh_recs, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out})
         b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -264,6 +264,7 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
             return fail(ctx, RTHIP_E_BADARG, "a non-empty array has a NULL pointer");
         const uint64_t n_shapes = s->n_spheres + s->n_planes + s->n_triangles;
         if (n_shapes >= 0x7fffffffull) return fail(ctx, RTHIP_E_BADARG, "too many shapes");
+        if (s->n_spheres + s->n_triangles >= RT_BVH_MAX_PRIMS) return fail(ctx, RTHIP_E_BADARG, "too many spheres + triangles for the BVH (2^29)");
         if (s->n_materials >= 0x7fffffffull || s->n_textures >= 0x7fffffffull || s->n_lights > 1024)
             return fail(ctx, RTHIP_E_BADARG, "too many materials/textures/lights");
         // ---- validate ----
@@ -393,21 +394,38 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
         // ---- linear BVH over spheres + triangles for big scenes ----
         std::vector<DevBvhNode> nodes;
         std::vector<uint32_t> prims;
-        if (s->n_spheres + s->n_triangles > RT_BVH_THRESHOLD) rt_build_bvh(s, nodes, prims);
+        uint32_t bvh_levels = 0;
+        if (s->n_spheres + s->n_triangles > RT_BVH_THRESHOLD) bvh_levels = rt_build_bvh(s, nodes, prims);
+        if (bvh_levels > RT_BVH_MAX_DEPTH) return fail(ctx, RTHIP_E_INTERNAL, "BVH deeper than the traversal stack");
         if ((st = upload(ctx, ctx->bvh_nodes, nodes.data(), nodes.size() * sizeof(DevBvhNode)))) return st;
-        if ((st = upload(ctx, ctx->bvh_prims, prims.data(), prims.size() * sizeof(uint32_t)))) return st;
+        // primitives in leaf order, self-contained records (geometry + global shape index + kind)
+        std::vector<rt_f4> recs(3 * prims.size());
+        for (size_t j = 0; j < prims.size(); j++) {
+            const uint32_t id = prims[j];
+            if (id < s->n_spheres) {
+                recs[3 * j + 0] = rt_f4{geom[id].x, geom[id].y, geom[id].z, bits_f(id)};
+                recs[3 * j + 1] = rt_f4{geom[id].w, 0.0f, 0.0f, bits_f(0u)};
+                recs[3 * j + 2] = rt_f4{0.0f, 0.0f, 0.0f, 0.0f};
+            } else {
+                const size_t t = id - s->n_spheres;
+                recs[3 * j + 0] = rt_f4{tr[3 * t].x, tr[3 * t].y, tr[3 * t].z, bits_f(uint32_t(s->n_spheres + s->n_planes + t))};
+                recs[3 * j + 1] = rt_f4{tr[3 * t + 1].x, tr[3 * t + 1].y, tr[3 * t + 1].z, bits_f(1u)};
+                recs[3 * j + 2] = tr[3 * t + 2];
+            }
+        }
+        if ((st = upload(ctx, ctx->bvh_recs, recs.data(), recs.size() * sizeof(rt_f4)))) return st;
 
         KernelParams &k = ctx->base;
         k.n_spheres = uint32_t(s->n_spheres), k.n_planes = uint32_t(s->n_planes), k.n_tris = uint32_t(s->n_triangles);
         k.n_lights = uint32_t(s->n_lights);
         k.n_bvh_nodes = uint32_t(nodes.size());
-        k.n_bvh_spheres = uint32_t(s->n_spheres);
+        k.bvh_levels = bvh_levels;
         k.sph_geom = (const rt_f4 *)ctx->sph_geom.p, k.sph_shade = (const rt_f4 *)ctx->sph_shade.p;
         k.pln_geom = (const rt_f4 *)ctx->pln_geom.p, k.tri_geom = (const rt_f4 *)ctx->tri_geom.p;
         k.materials = (const DevMaterial *)ctx->materials.p;
         k.texels = (const uint32_t *)ctx->texels.p, k.tex_info = (const DevTexInfo *)ctx->tex_info.p;
         k.lights = (const DevLight *)ctx->lights.p;
-        k.bvh_nodes = (const DevBvhNode *)ctx->bvh_nodes.p, k.bvh_prims = (const uint32_t *)ctx->bvh_prims.p;
+        k.bvh_nodes = (const DevBvhNode *)ctx->bvh_nodes.p, k.bvh_recs = (const rt_f4 *)ctx->bvh_recs.p;
         ctx->n_shapes = n_shapes;
         ctx->have_scene = true;
         ctx->nb_samples = 0;  // a new scene invalidates the running sum
