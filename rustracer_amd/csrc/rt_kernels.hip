@@ -463,38 +463,27 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
             r.tmin = RT_T_MIN * len;
             r.tmax = RT_T_MAX * len;
         };
-        uint32_t key_own = rt_counter(__float_as_uint(pp_own.w), P.sample0, 0);  // !POOL: slot 0 of this pixel's next sample
-        auto new_path = [&](uint32_t pixel, uint32_t sample) {
-            rt_f4 pp;
-            if (POOL) {
-                pp = s_pix[pixel];
-                key = rt_counter(__float_as_uint(pp.w), sample, 0);
-            } else {
-                pp = pp_own;
-                key = key_own;
-                key_own += RT_RNG_SLOTS * RT_RNG_GOLDEN;
-            }
-            // lib.rs:282-285: x jitter first
-            const uint32_t hj = rt_mix32(key);
-            // u = (x + xi)/(W-1) = x/(W-1) + xi/(W-1): the per-pixel part is precomputed (s_pix)
-            const float ju = rt_unit(hj) * P.inv_wm1;
-            const float jv = rt_unit(rt_second(hj)) * P.inv_hm1;
-            r.o = cam_o;  // camera.rs:43-50
-            set_dir(mk3(fmaf(P.vx, jv, fmaf(P.hx, ju, pp.x)), fmaf(P.vy, jv, fmaf(P.hy, ju, pp.y)), fmaf(P.vz, jv, fmaf(P.hz, ju, pp.z))));
-            T = mk3(1.0f, 1.0f, 1.0f);
-            bounce = 0;
-            self = RT_NONE;
-            if (LIGHTS) Ld = mk3(0.0f, 0.0f, 0.0f);
-        };
         HitRec h;
         h.t = 0.0f, h.shape = RT_NONE, h.b1 = h.b2 = 0.0f;
         BvhState bs;           // MODE_BVH: the closest-hit query is resumable
         bs.ref = RT_BVH_DONE, bs.sp = 0, bs.inv_d = bs.noi = mk3(0.0f, 0.0f, 0.0f);
         bool tracing = false;  // ... and this lane's ray is still inside the tree
-        // One segment of the lane's path: closest hit, shading, next ray. Returns 0 = the path goes on,
-        // 1 = the path ended with radiance L, 2 (MODE_BVH) = the ray is parked inside the tree.
-        auto segment = [&](f3 &L) -> int {
+        // what shade() leaves behind for next_ray(): the hit point, the surface and the mirror direction
+        f3 p = cam_o, refl = mk3(0.0f, 0.0f, 0.0f);
+        float cosi = 0.0f;
+        Surface sf;
+        sf.n = sf.tm = mk3(0.0f, 0.0f, 0.0f), sf.param = sf.r1 = sf.inv_ior = sf.tu = sf.tv = sf.tw = 0.0f, sf.kind = sf.mat = 0;
+        bool dead = false;  // the last scatter absorbed the path (metal.rs:62-64): it ends, with L = T, at the next shade()
+        // First half of a segment: closest hit and shading. Returns 1 = the path ended with radiance L,
+        // 0 = it goes on (next_ray(false) scatters it), 2 (MODE_BVH) = the ray is parked inside the tree.
+        auto shade = [&](f3 &L) -> int {
             bool done;
+            if (dead) {  // None -> new_color alone, ray.rs:80
+                dead = false;
+                L = T;
+                if (LIGHTS) L = L + Ld;
+                return 1;
+            }
             if (MODE == MODE_BVH) {
                 if (!tracing) {
                     h.shape = RT_NONE;
@@ -524,9 +513,8 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                 done = true;
                 if (STATS) cnt[RT_STAT_SKY]++;
             } else {
-                const f3 p = fma3(r.d, h.t, r.o);  // ray.rs:30-32
+                p = fma3(r.d, h.t, r.o);  // ray.rs:30-32
                 // ---- the surface: normal + material (collision.rs:29-43) ----
-                Surface sf;
                 if (h.shape < P.n_spheres) {
                     rt_f4 r0, r1, r2;
                     if constexpr (MODE == MODE_LDS) {  // kept apart so that the LDS reads stay ds_read_b128 (no generic pointer)
@@ -592,8 +580,8 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                     L = T * c;
                     done = true;
                 } else {
-                    const float cosi = dot(r.d, sf.n);
-                    const f3 refl = fma3(sf.n, -2.0f * cosi, r.d);  // metal.rs:27-29, dielectric.rs:28-30 (unit incoming direction)
+                    cosi = dot(r.d, sf.n);
+                    refl = fma3(sf.n, -2.0f * cosi, r.d);  // metal.rs:27-29, dielectric.rs:28-30 (unit incoming direction)
                     if (LIGHTS && sf.kind != RTHIP_MAT_DIELECTRIC) {
                         // extension (RTHIP_F_POINT_LIGHTS): Lambert N.L on Lambertian, Phong (R.L)^s on Metal, one shadow ray per light
                         const DevMaterial m = P.materials[sf.mat];
@@ -625,60 +613,93 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                         Ld = Ld + T * sum;
                     }
                     T = T * sf.tm;  // scatter: albedo/pi * 3 (lambertian_diffuse.rs:53-66, metal.rs:45-56, dielectric.rs:56-66)
-                    key += RT_RNG_GOLDEN;
-                    const uint32_t hb = rt_mix32(key);  // RNG slot 1 + bounce
-                    // Lambertian: n + w (lambertian_diffuse.rs:68-73); Metal: reflect + fuzz*w (metal.rs:59-60): one shared unit vector
-                    const f3 w = random_unit_vector(hb);
-                    const bool lambert = sf.kind == RTHIP_MAT_LAMBERTIAN;
-                    const f3 base = lambert ? sf.n : refl;
-                    const float wf = lambert ? 1.0f : sf.param;
-                    f3 nd = fma3(w, wf, base);
-                    // metal.rs:62-64: absorbed if the new direction points into the surface (never true for n + w)
-                    done = dot(nd, sf.n) < 0.0f;
-                    if (sf.kind == RTHIP_MAT_DIELECTRIC) {  // dielectric.rs:68-98
-                        // dot_product = direction . normal with the UN-normalised direction; len() is the element count 3: dielectric.rs:74-83
-                        const float len = r.tmin * (1.0f / RT_T_MIN);  // |direction|
-                        const float dp = cosi * len;
-                        const bool inside = dp > 0.0f;
-                        const float eta = inside ? sf.param : sf.inv_ior;
-                        const float cosine = (inside ? sf.param * dp : -dp) * (1.0f / 3.0f);
-                        // outward_normal = inside ? -n : n, so unit . outward_normal = -|cosi|
-                        const float dt = -fabsf(cosi);
-                        const float k = fmaf(-eta * eta, fmaf(-dt, dt, 1.0f), 1.0f);  // dielectric.rs:39
-                        const float om = 1.0f - cosine;
-                        const float om2 = om * om;
-                        const float prob = (k < 0.0f) ? 1.0f : fmaf(1.0f - sf.r1, om2 * om2 * om, sf.r1);  // dielectric.rs:47-52,87-92
-                        const float xi = rt_unit(hb);                                                      // dielectric.rs:94
-                        // refracted = (unit - on*dt)*eta - on*sqrt(k)   (dielectric.rs:44)
-                        const float sgn = inside ? -1.0f : 1.0f;
-                        const float cn = sgn * (-dt * eta - fast_sqrt(k));
-                        const f3 refr = fma3(sf.n, cn, r.d * eta);
-                        nd = (prob > xi) ? refl : refr;
-                        done = false;
-                    }
-                    if (done) L = T;  // None -> new_color alone, ray.rs:80
-                    r.o = p;
-                    set_dir(nd);
-                    self = h.shape;
-                    bounce++;
+                    done = false;
                 }
             }
             if (done && LIGHTS) L = L + Ld;
             return done ? 1 : 0;
         };
+        // Second half: the lane's next ray — the scattered ray of the surface shade() left behind, or
+        // (fresh) the primary ray of a new sample. Both need one RNG pair and one normalisation; sharing
+        // them halves that cost in a wave where some lanes continue and the others start a new path.
+        uint32_t key_own = rt_counter(__float_as_uint(pp_own.w), P.sample0, 0);  // !POOL: slot 0 of this pixel's next sample
+        auto next_ray = [&](bool fresh, uint32_t pixel, uint32_t sample) {
+            rt_f4 pp = pp_own;
+            uint32_t k = key + RT_RNG_GOLDEN;  // RNG slot 1 + bounce
+            if (POOL) {
+                if (fresh) {
+                    pp = s_pix[pixel];
+                    k = rt_counter(__float_as_uint(pp.w), sample, 0);
+                }
+            } else {
+                k = fresh ? key_own : k;
+                key_own += fresh ? RT_RNG_SLOTS * RT_RNG_GOLDEN : 0u;
+            }
+            key = k;
+            const uint32_t hb = rt_mix32(k);
+            const float ua = rt_unit(hb), ub = rt_unit(rt_second(hb));
+            f3 nd;
+            if (fresh) {
+                // lib.rs:282-285 (x jitter first): u = (x + xi)/(W-1) = x/(W-1) + xi/(W-1), the per-pixel part is precomputed
+                const float ju = ua * P.inv_wm1, jv = ub * P.inv_hm1;
+                nd = mk3(fmaf(P.vx, jv, fmaf(P.hx, ju, pp.x)), fmaf(P.vy, jv, fmaf(P.hy, ju, pp.y)), fmaf(P.vz, jv, fmaf(P.hz, ju, pp.z)));
+                r.o = cam_o;  // camera.rs:43-50
+                T = mk3(1.0f, 1.0f, 1.0f);
+                bounce = 0;
+                self = RT_NONE;
+                if (LIGHTS) Ld = mk3(0.0f, 0.0f, 0.0f);
+            } else {
+                // random_unit_vector — lambertian_diffuse.rs:39-45, metal.rs:31-37 (a first, then z); v_sin/v_cos take revolutions
+                const float z = fmaf(2.0f, ub, -1.0f);
+                const float rr = fast_sqrt(fmaf(-z, z, 1.0f));
+                const f3 w = mk3(rr * __builtin_amdgcn_cosf(ua), rr * __builtin_amdgcn_sinf(ua), z);
+                // Lambertian: n + w (lambertian_diffuse.rs:68-73); Metal: reflect + fuzz*w (metal.rs:59-60): one shared unit vector
+                const bool lambert = sf.kind == RTHIP_MAT_LAMBERTIAN;
+                const f3 base = lambert ? sf.n : refl;
+                const float wf = lambert ? 1.0f : sf.param;
+                nd = fma3(w, wf, base);
+                // metal.rs:62-64: absorbed if the new direction points into the surface (never true for n + w)
+                dead = dot(nd, sf.n) < 0.0f;
+                if (sf.kind == RTHIP_MAT_DIELECTRIC) {  // dielectric.rs:68-98
+                    // dot_product = direction . normal with the UN-normalised direction; len() is the element count 3: dielectric.rs:74-83
+                    const float len = r.tmin * (1.0f / RT_T_MIN);  // |direction|
+                    const float dp = cosi * len;
+                    const bool inside = dp > 0.0f;
+                    const float eta = inside ? sf.param : sf.inv_ior;
+                    const float cosine = (inside ? sf.param * dp : -dp) * (1.0f / 3.0f);
+                    // outward_normal = inside ? -n : n, so unit . outward_normal = -|cosi|
+                    const float dt = -fabsf(cosi);
+                    const float kk = fmaf(-eta * eta, fmaf(-dt, dt, 1.0f), 1.0f);  // dielectric.rs:39
+                    const float om = 1.0f - cosine;
+                    const float om2 = om * om;
+                    const float prob = (kk < 0.0f) ? 1.0f : fmaf(1.0f - sf.r1, om2 * om2 * om, sf.r1);  // dielectric.rs:47-52,87-92
+                    // refracted = (unit - on*dt)*eta - on*sqrt(k)   (dielectric.rs:44); the coin is ua (dielectric.rs:94)
+                    const float sgn = inside ? -1.0f : 1.0f;
+                    const float cn = sgn * (-dt * eta - fast_sqrt(kk));
+                    const f3 refr = fma3(sf.n, cn, r.d * eta);
+                    nd = (prob > ua) ? refl : refr;
+                    dead = false;
+                }
+                r.o = p;
+                self = h.shape;
+                bounce++;
+            }
+            set_dir(nd);
+        };
         if constexpr (!POOL) {
             // ---- lane = pixel: path regeneration over the pixel's samples ----
             if (active) {
                 uint32_t s_left = P.spp;
-                new_path(lane, 0);
+                next_ray(true, lane, 0);
                 for (;;) {
                     f3 L;
-                    if (segment(L)) {
+                    const bool fresh = shade(L) != 0;
+                    if (fresh) {
                         acc = acc + L;  // lib.rs:287
                         cnt[RT_STAT_PATHS]++;
                         if (--s_left == 0) break;
-                        new_path(lane, 0);
                     }
+                    next_ray(fresh, lane, 0);
                 }
             }
         } else {
@@ -694,19 +715,22 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                         if (idx < total && ((amask >> (idx & 63u)) & 1ull)) {
                             item = idx;
                             have = true;
-                            new_path(idx & 63u, P.sample0 + s_base + (idx >> 6));
+                            next_ray(true, idx & 63u, P.sample0 + s_base + (idx >> 6));
                         }
                     }
                     next = min(next + uint32_t(__popcll(need)), total);
                     if (__ballot(have) == 0ull) break;
                     if (have) {
                         f3 L;
-                        if (segment(L) == 1) {
+                        const int st = shade(L);
+                        if (st == 1) {
                             s_L[item] = L.x;  // lib.rs:287, summed in sample order below
                             s_L[plane + item] = L.y;
                             s_L[2u * plane + item] = L.z;
                             cnt[RT_STAT_PATHS]++;
                             have = false;
+                        } else if (st == 0) {
+                            next_ray(false, 0, 0);
                         }
                     }
                 }
