@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RTHIP_ABI_VERSION 1
+#define RTHIP_ABI_VERSION 2
 
 typedef enum rthip_status {
     RTHIP_OK = 0,
@@ -133,8 +133,16 @@ enum {
     RTHIP_F_ACCUMULATE = 1u << 0,   /* add to the context's running sum (lib.rs:289-294) instead of starting over */
     RTHIP_F_POINT_LIGHTS = 1u << 1, /* extension: direct light + shadow rays at every scattering hit */
     RTHIP_F_COUNT_STATS = 1u << 2,  /* run the instrumented kernel and fill rthip_stats counters */
-    RTHIP_F_NO_BVH = 1u << 3        /* force the brute-force linear scan (ray.rs:47-67) even for big scenes */
+    RTHIP_F_NO_BVH = 1u << 3,       /* force the brute-force linear scan (ray.rs:47-67) even for big scenes */
+    RTHIP_F_ADAPTIVE = 1u << 4      /* progressive passes with the convergence rule of lib.rs:276-313: a pixel whose 8-bit
+                                       colour was the same in 5 consecutive passes (same_color_count > 3, lib.rs:244,309)
+                                       becomes GenerationStatus::Final and is skipped by every later pass (lib.rs:277-279):
+                                       no rays, running sum and colour unchanged. Passes after the first must also set
+                                       RTHIP_F_ACCUMULATE; they trace a compacted work-list of the pixels not yet Final. */
 };
+
+/* GenerationStatus (lib.rs:59-64) as reported by rthip_pixel_status */
+enum { RTHIP_STATUS_NOT_STARTED = 0, RTHIP_STATUS_COPY_NEAR_PIXEL = 1 /* never produced: generator-side */, RTHIP_STATUS_UNSTABLE = 2, RTHIP_STATUS_FINAL = 3 };
 
 typedef struct rthip_render_params {
     uint32_t width;       /* full image width  (u = (x+xi)/(width-1),  lib.rs:282-283) */
@@ -163,6 +171,8 @@ typedef struct rthip_stats {
     uint64_t nb_samples;   /* samples accumulated per pixel so far (PixelCache.nb_samples, lib.rs:72) */
     double kernel_ms;      /* device time of the render kernel(s), HIP events */
     double d2h_ms;         /* device->host copy of the outputs (rthip_render only) */
+    uint64_t pixels_traced; /* RTHIP_F_ADAPTIVE: pixels that received samples this pass (all owned pixels otherwise) */
+    uint64_t pixels_final;  /* RTHIP_F_ADAPTIVE: owned pixels that are Final after this pass */
 } rthip_stats;
 
 typedef struct rthip_ctx rthip_ctx;
@@ -212,6 +222,12 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *params, void 
 /* Forget the running sum: PixelRenderer::invalidate_pixels / RandomGenerator::invalidate_pixels
  * (lib.rs:79,120-138). */
 int rthip_reset_accum(rthip_ctx *ctx);
+
+/* RTHIP_F_ADAPTIVE: PixelColor.status (lib.rs:17-22,312) of every owned pixel after the last pass, one
+ * byte per pixel (RTHIP_STATUS_*), owned_rows*width bytes in the layout of the image outputs. This is what
+ * the reference hands to PixelRenderer::set_pixel beside r,g,b (standalone/src/renderers/pixels.rs:254 draws it).
+ * same_color_count_out (nullable): PixelCache.same_color_count (lib.rs:71). RTHIP_E_STATE if no adaptive pass ran. */
+int rthip_pixel_status(rthip_ctx *ctx, uint8_t *status_out, uint8_t *same_color_count_out);
 
 /* Raytracer::get_shape (lib.rs:262-267): un-jittered primary ray through pixel (x, y) of a
  * width x height image; *out_shape = index of the closest shape, or -1 for a miss. */

@@ -118,6 +118,35 @@ def project_ray(flat, origin, direction, max_depth=50, key=0, point_lights=False
     return np.array(rgb), seg.value
 
 
+class AdaptiveState:
+    """PixelCache arrays (lib.rs:66-73) carried between the passes of render_adaptive."""
+
+    def __init__(self, w, h):
+        self.rgba = np.zeros((h, w, 4), np.uint8)
+        self.sum = np.zeros((h, w, 3), np.float64)
+        self.status = np.zeros((h, w), np.uint8)
+        self.same_color_count = np.zeros((h, w), np.uint8)
+        self.last_color = np.zeros((h, w, 3), np.uint8)
+        self.nb_samples = np.zeros((h, w), np.uint64)
+
+
+def render_adaptive(flat, cam: abi.Camera, params: abi.RenderParams, state: AdaptiveState, precision=64, threads=0):
+    """One progressive pass of generate_pixel over every pixel with the convergence rule (lib.rs:276-313).
+    params.flags must carry F_ACCUMULATE on every pass but the first. Returns the stats dict."""
+    if threads <= 0:
+        threads = hw_threads()
+    st = abi.Stats()
+    fn = lib().oracle_render_adaptive
+    fn.restype = C.c_int
+    rc = fn(C.byref(flat.desc), C.byref(cam), C.byref(params), None, C.c_int(precision), C.c_int(threads),
+            C.c_void_p(state.rgba.ctypes.data), C.c_void_p(state.sum.ctypes.data), C.c_void_p(state.status.ctypes.data),
+            C.c_void_p(state.same_color_count.ctypes.data), C.c_void_p(state.last_color.ctypes.data),
+            C.c_void_p(state.nb_samples.ctypes.data), C.byref(st))
+    if rc != 0:
+        raise ValueError("oracle_render_adaptive: bad argument")
+    return st.as_dict()
+
+
 def render(flat, cam: abi.Camera, params: abi.RenderParams, precision=64, threads=0, crop=None, prior_samples=0, sum_in=None):
     """Returns (rgba8 (h,w,4) u8, sum (h,w,3) f64, stats dict, seconds). Rows are y-up (row 0 = bottom)."""
     if threads <= 0:

@@ -39,6 +39,22 @@ int oracle_render(const rthip_scene_desc *scene, const rthip_camera *cam, const 
     return 0;
 }
 
+// The same with the PixelCache arrays of the progressive rule (lib.rs:276-313): one call = one pass over every pixel.
+// status/same_color_count/last_color(3 per pixel)/nb_samples: crop_w*crop_h entries, zeroed by the caller before pass 1.
+int oracle_render_adaptive(const rthip_scene_desc *scene, const rthip_camera *cam, const rthip_render_params *p, const uint32_t *crop,
+                           int precision, int threads, uint8_t *rgba8, double *sum_io, uint8_t *status, uint8_t *same_color_count,
+                           uint8_t *last_color, uint64_t *nb_samples, rthip_stats *stats) {
+    if (!scene || !cam || !p || p->width < 2 || p->height < 2 || p->spp == 0 || !status || !same_color_count || !last_color || !nb_samples) return -1;
+    PixelCaches c{status, same_color_count, last_color, nb_samples};
+    if (precision == 64)
+        render<double>(*scene, *cam, *p, crop, 0, threads, rgba8, sum_io, stats, &c);
+    else if (precision == 32)
+        render<float>(*scene, *cam, *p, crop, 0, threads, rgba8, sum_io, stats, &c);
+    else
+        return -1;
+    return 0;
+}
+
 // ---- known-answer accessors ----
 void oracle_camera_lookat(double x, double y, double z, const double lookat[3], rthip_camera *out) { camera_lookat(x, y, z, lookat, out); }
 

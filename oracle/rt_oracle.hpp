@@ -567,28 +567,55 @@ static V3<Real> direct_light(const Scene<Real> &scene, const Hit<Real> &hit, con
 // crop = {x0, y0, w, h} restricts the pass to a window (CPU-baseline sampling); output
 // buffers then hold w*h pixels.
 // ----------------------------------------------------------------------------------------
+// PixelCache (lib.rs:66-73) of every pixel for the progressive rule of lib.rs:276-313 (RTHIP_F_ADAPTIVE); arrays of
+// crop_w*crop_h entries owned by the caller, all zero before the first pass.
+struct PixelCaches {
+    uint8_t *status;            // GenerationStatus: 0 NotStarted, 2 Unstable, 3 Final
+    uint8_t *same_color_count;  // lib.rs:71
+    uint8_t *last_color;        // 3 per pixel, valid once status != NotStarted (last_color: Option<PixelColor>)
+    uint64_t *nb_samples;       // lib.rs:72 — per pixel: a Final pixel stops counting
+};
+
 template <class Real>
 static void render(const rthip_scene_desc &desc, const rthip_camera &cam, const rthip_render_params &p, const uint32_t *crop,
-                   uint64_t prior_samples, int threads, uint8_t *rgba8, double *sum_io, rthip_stats *stats_out) {
+                   uint64_t prior_samples, int threads, uint8_t *rgba8, double *sum_io, rthip_stats *stats_out,
+                   const PixelCaches *caches = nullptr) {
     Scene<Real> scene(desc);
     const uint32_t x0 = crop ? crop[0] : 0, y0 = crop ? crop[1] : 0;
     const uint32_t cw = crop ? crop[2] : p.width, ch = crop ? crop[3] : p.height;
     const bool accumulate = (p.flags & RTHIP_F_ACCUMULATE) != 0;
     const bool lights = (p.flags & RTHIP_F_POINT_LIGHTS) != 0 && !scene.lights.empty();
-    const uint64_t nb_samples = (accumulate ? prior_samples : 0) + p.spp;
-    const uint32_t sample0 = accumulate ? uint32_t(prior_samples) : 0;
+    const uint64_t nb_samples_all = (accumulate ? prior_samples : 0) + p.spp;
+    const uint32_t sample0_all = accumulate ? uint32_t(prior_samples) : 0;
+    uint64_t n_traced = 0, n_final = 0;
     rthip_stats total;
     std::memset(&total, 0, sizeof total);
 #pragma omp parallel num_threads(threads > 0 ? threads : 1)
     {
         rthip_stats st;
         std::memset(&st, 0, sizeof st);
-#pragma omp for schedule(dynamic, 1)
+#pragma omp for schedule(dynamic, 1) reduction(+ : n_traced, n_final)
         for (int64_t ly = 0; ly < int64_t(ch); ly++) {
             const uint32_t y = y0 + uint32_t(ly);
             for (uint32_t lx = 0; lx < cw; lx++) {
                 const uint32_t x = x0 + lx;
                 const uint32_t pixel_index = y * p.width + x;
+                const size_t o = size_t(ly) * cw + lx;
+                uint64_t nb_samples = nb_samples_all;
+                uint32_t sample0 = sample0_all;
+                if (caches) {
+                    if (caches->status[o] == 3) {  // lib.rs:277-279: a Final pixel is left alone (its last colour stays on screen)
+                        if (rgba8) {
+                            rgba8[o * 4 + 0] = caches->last_color[o * 3 + 0], rgba8[o * 4 + 1] = caches->last_color[o * 3 + 1];
+                            rgba8[o * 4 + 2] = caches->last_color[o * 3 + 2], rgba8[o * 4 + 3] = 255;
+                        }
+                        n_final++;
+                        continue;
+                    }
+                    sample0 = accumulate ? uint32_t(caches->nb_samples[o]) : 0;
+                    nb_samples = (accumulate ? caches->nb_samples[o] : 0) + p.spp;  // lib.rs:293
+                    caches->nb_samples[o] = nb_samples;
+                }
                 V3<Real> samples_color(0, 0, 0);
                 for (uint32_t s = 0; s < p.spp; s++) {
                     const uint32_t key = path_key(p.seed, pixel_index, sample0 + s);
@@ -601,16 +628,30 @@ static void render(const rthip_scene_desc &desc, const rthip_camera &cam, const 
                     samples_color = samples_color + project_ray(scene, r, p.max_depth, key, lights, &st);  // lib.rs:287
                     st.paths++;
                 }
-                const size_t o = size_t(ly) * cw + lx;
                 if (accumulate && sum_io) {  // lib.rs:289-291
                     samples_color = samples_color + V3<Real>(Real(sum_io[o * 3 + 0]), Real(sum_io[o * 3 + 1]), Real(sum_io[o * 3 + 2]));
                 }
                 if (sum_io) { sum_io[o * 3 + 0] = double(samples_color.x); sum_io[o * 3 + 1] = double(samples_color.y); sum_io[o * 3 + 2] = double(samples_color.z); }
+                const uint8_t col[3] = {tonemap_channel(samples_color.x, nb_samples), tonemap_channel(samples_color.y, nb_samples),
+                                        tonemap_channel(samples_color.z, nb_samples)};
                 if (rgba8) {
-                    rgba8[o * 4 + 0] = tonemap_channel(samples_color.x, nb_samples);
-                    rgba8[o * 4 + 1] = tonemap_channel(samples_color.y, nb_samples);
-                    rgba8[o * 4 + 2] = tonemap_channel(samples_color.z, nb_samples);
+                    rgba8[o * 4 + 0] = col[0], rgba8[o * 4 + 1] = col[1], rgba8[o * 4 + 2] = col[2];
                     rgba8[o * 4 + 3] = 255;
+                }
+                if (caches) {  // lib.rs:300-313
+                    n_traced++;
+                    if (caches->status[o] != 0) {  // last_color is Some
+                        const uint8_t *last = &caches->last_color[o * 3];
+                        if (last[0] == col[0] && last[1] == col[1] && last[2] == col[2]) caches->same_color_count[o] += 1;
+                        else caches->same_color_count[o] = 0;
+                    } else {
+                        caches->status[o] = 2;  // Unstable
+                    }
+                    if (caches->same_color_count[o] > 3) {  // MAX_SIMILAR_SAMPLE_FOR_A_PIXEL
+                        caches->status[o] = 3;
+                        n_final++;
+                    }
+                    caches->last_color[o * 3 + 0] = col[0], caches->last_color[o * 3 + 1] = col[1], caches->last_color[o * 3 + 2] = col[2];
                 }
             }
         }
@@ -623,7 +664,9 @@ static void render(const rthip_scene_desc &desc, const rthip_camera &cam, const 
         }
     }
     total.rows = ch;
-    total.nb_samples = nb_samples;
+    total.nb_samples = nb_samples_all;
+    total.pixels_traced = caches ? n_traced : uint64_t(cw) * ch;
+    total.pixels_final = n_final;
     if (stats_out) *stats_out = total;
 }
 

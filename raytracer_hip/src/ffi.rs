@@ -1,5 +1,5 @@
 //! #[repr(C)] mirrors of include/rthip.h and the extern "C" entry points. Keep in sync with the header
-//! (RTHIP_ABI_VERSION = 1); tests/test_abi.py pins the struct sizes the same way.
+//! (RTHIP_ABI_VERSION = 2); tests/test_abi.py pins the struct sizes the same way.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -12,6 +12,10 @@ pub const RTHIP_F_ACCUMULATE: u32 = 1 << 0;
 pub const RTHIP_F_POINT_LIGHTS: u32 = 1 << 1;
 pub const RTHIP_F_COUNT_STATS: u32 = 1 << 2;
 pub const RTHIP_F_NO_BVH: u32 = 1 << 3;
+pub const RTHIP_F_ADAPTIVE: u32 = 1 << 4;
+pub const RTHIP_STATUS_NOT_STARTED: u8 = 0;
+pub const RTHIP_STATUS_UNSTABLE: u8 = 2;
+pub const RTHIP_STATUS_FINAL: u8 = 3;
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct rthip_material { pub kind: u32, pub texture: u32, pub albedo: [f64; 3], pub param: f64, pub shininess: f64 }
@@ -46,6 +50,7 @@ pub struct rthip_stats {
     pub paths: u64, pub rays: u64, pub sphere_tests: u64, pub plane_tests: u64, pub tri_tests: u64, pub node_tests: u64,
     pub hits: [u64; 4], pub sky_evals: u64, pub shadow_rays: u64, pub rows: u64, pub nb_samples: u64,
     pub kernel_ms: f64, pub d2h_ms: f64,
+    pub pixels_traced: u64, pub pixels_final: u64,
 }
 pub enum rthip_ctx {}
 
@@ -62,6 +67,7 @@ extern "C" {
     pub fn rthip_render_device(ctx: *mut rthip_ctx, params: *const rthip_render_params, d_rgba8: *mut c_void, d_accum: *mut c_void,
                                hip_stream: *mut c_void, stats: *mut rthip_stats) -> c_int;
     pub fn rthip_reset_accum(ctx: *mut rthip_ctx) -> c_int;
+    pub fn rthip_pixel_status(ctx: *mut rthip_ctx, status_out: *mut u8, same_color_count_out: *mut u8) -> c_int;
     pub fn rthip_pick(ctx: *mut rthip_ctx, width: u32, height: u32, x: f64, y: f64, out_shape: *mut i64) -> c_int;
     pub fn rthip_algorithmic_flops(stats: *const rthip_stats) -> f64;
     pub fn rthip_last_error(ctx: *const rthip_ctx) -> *const c_char;

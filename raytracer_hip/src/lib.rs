@@ -64,6 +64,7 @@ pub struct HipRaytracer {
     height: f64,
     seed: u32,
     uploaded_camera: Option<rthip_camera>,
+    status: Vec<u8>, // RTHIP_STATUS_* per pixel after the last adaptive pass
 }
 unsafe impl Send for HipRaytracer {} // one caller thread at a time, like the reference's single render thread
 
@@ -72,7 +73,7 @@ impl HipRaytracer {
         let mut ctx = std::ptr::null_mut();
         let st = unsafe { rthip_create(device, &mut ctx) };
         if st != 0 { return Err(err(std::ptr::null(), st)); }
-        Ok(HipRaytracer { camera: Camera::new(-1.8, 1.0, 2.0), ctx, width, height, seed, uploaded_camera: None })
+        Ok(HipRaytracer { camera: Camera::new(-1.8, 1.0, 2.0), ctx, width, height, seed, uploaded_camera: None, status: Vec::new() })
     }
 
     pub fn upload(&mut self, scene: &SceneDesc) -> Result<()> {
@@ -131,7 +132,30 @@ impl HipRaytracer {
         Ok(stats)
     }
 
-    pub fn invalidate_pixels(&mut self) -> Result<()> { self.check(unsafe { rthip_reset_accum(self.ctx) }) }
+    /// One progressive pass with the convergence rule of `generate_pixel` (lib.rs:276-313): pixels that are already
+    /// `Final` are skipped on the device and get no `set_pixel`; the others are reported with their new status.
+    pub fn render_adaptive_pass<S: PixelRenderer>(&mut self, samples: u64, max_depth: u32, first: bool, renderer: &mut S) -> Result<rthip_stats> {
+        self.sync_camera()?;
+        let (w, h) = (self.width as u32, self.height as u32);
+        let npx = (w as usize) * (h as usize);
+        if first || self.status.len() != npx { self.status = vec![RTHIP_STATUS_NOT_STARTED; npx]; }
+        let before = self.status.clone();
+        let p = rthip_render_params { width: w, height: h, spp: samples as u32, max_depth, seed: self.seed,
+                                      flags: RTHIP_F_ADAPTIVE | if first { 0 } else { RTHIP_F_ACCUMULATE }, ..Default::default() };
+        let mut rgba = vec![0u8; npx * 4];
+        let mut stats = rthip_stats::default();
+        self.check(unsafe { rthip_render(self.ctx, &p, rgba.as_mut_ptr(), std::ptr::null_mut(), &mut stats) })?;
+        self.check(unsafe { rthip_pixel_status(self.ctx, self.status.as_mut_ptr(), std::ptr::null_mut()) })?;
+        for i in 0..npx {
+            if before[i] == RTHIP_STATUS_FINAL { continue; } // lib.rs:277-279
+            let status = if self.status[i] == RTHIP_STATUS_FINAL { GenerationStatus::Final } else { GenerationStatus::Unstable };
+            renderer.set_pixel(PixelPosition { x: i % w as usize, y: i / w as usize },
+                               PixelColor { r: rgba[i * 4], g: rgba[i * 4 + 1], b: rgba[i * 4 + 2], status });
+        }
+        Ok(stats)
+    }
+
+    pub fn invalidate_pixels(&mut self) -> Result<()> { self.status.clear(); self.check(unsafe { rthip_reset_accum(self.ctx) }) }
 
     /// Raytracer::get_shape (lib.rs:262-267)
     pub fn get_shape(&mut self, x: f64, y: f64) -> Result<Option<usize>> {

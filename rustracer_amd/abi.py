@@ -11,7 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # rthip_status
 OK, E_BADARG, E_HIP, E_OOM, E_NODEVICE, E_STATE, E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
@@ -22,6 +22,8 @@ F_ACCUMULATE = 1 << 0
 F_POINT_LIGHTS = 1 << 1
 F_COUNT_STATS = 1 << 2
 F_NO_BVH = 1 << 3
+F_ADAPTIVE = 1 << 4
+STATUS_NOT_STARTED, STATUS_COPY_NEAR_PIXEL, STATUS_UNSTABLE, STATUS_FINAL = 0, 1, 2, 3  # GenerationStatus, lib.rs:59-64
 
 _d3 = C.c_double * 3
 
@@ -74,7 +76,8 @@ class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("sphere_tests", C.c_uint64),
                 ("plane_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("node_tests", C.c_uint64),
                 ("hits", C.c_uint64 * 4), ("sky_evals", C.c_uint64), ("shadow_rays", C.c_uint64),
-                ("rows", C.c_uint64), ("nb_samples", C.c_uint64), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double)]
+                ("rows", C.c_uint64), ("nb_samples", C.c_uint64), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double),
+                ("pixels_traced", C.c_uint64), ("pixels_final", C.c_uint64)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if n == "hits" else getattr(self, n)) for n, _ in self._fields_}
@@ -92,6 +95,7 @@ SYMBOLS = {
     "rthip_render": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, _P(Stats)]),
     "rthip_render_device": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]),
     "rthip_reset_accum": (C.c_int, [C.c_void_p]),
+    "rthip_pixel_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "rthip_pick": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _P(C.c_int64)]),
     "rthip_algorithmic_flops": (C.c_double, [_P(Stats)]),
     "rthip_last_error": (C.c_char_p, [C.c_void_p]),

@@ -262,7 +262,33 @@ public:
                 }
         return st;
     }
-    void invalidate_pixels() { check(rthip_reset_accum(ctx_)); }
+    // One progressive pass with the reference's convergence rule (lib.rs:276-313, RTHIP_F_ADAPTIVE): `first` starts a new
+    // running sum. As in generate_pixel, set_pixel is called only for the pixels that were not Final before the pass, with
+    // their status after it (Unstable, or Final on the pass that froze them).
+    rthip_stats render_adaptive_pass(uint64_t samples, uint32_t max_depth, PixelRenderer *renderer, bool first,
+                                     std::vector<uint8_t> *rgba8_out = nullptr) {
+        const size_t npx = size_t(width_) * size_t(height_);
+        if (first || status_.size() != npx) status_.assign(npx, uint8_t(RTHIP_STATUS_NOT_STARTED));
+        const std::vector<uint8_t> before = status_;
+        std::vector<uint8_t> local;
+        std::vector<uint8_t> &img = rgba8_out ? *rgba8_out : local;
+        rthip_stats st = render(samples, max_depth, nullptr, !first, RTHIP_F_ADAPTIVE, &img);
+        check(rthip_pixel_status(ctx_, status_.data(), nullptr));
+        if (renderer)
+            for (size_t y = 0; y < size_t(height_); y++)
+                for (size_t x = 0; x < size_t(width_); x++) {
+                    const size_t i = y * size_t(width_) + x;
+                    if (before[i] == RTHIP_STATUS_FINAL) continue;  // lib.rs:277-279
+                    const uint8_t *px = &img[i * 4];
+                    renderer->set_pixel({x, y}, {px[0], px[1], px[2], status_[i] == RTHIP_STATUS_FINAL ? GenerationStatus::Final : GenerationStatus::Unstable});
+                }
+        return st;
+    }
+    const std::vector<uint8_t> &pixel_status() const { return status_; }
+    void invalidate_pixels() {
+        check(rthip_reset_accum(ctx_));
+        status_.clear();
+    }
 
     // Raytracer::get_shape — lib.rs:262-267; -1 = None
     int64_t get_shape(double x, double y) {
@@ -285,6 +311,7 @@ private:
     rthip_ctx *ctx_ = nullptr;
     double width_, height_;
     uint32_t seed_;
+    std::vector<uint8_t> status_;  // RTHIP_STATUS_* per pixel after the last adaptive pass
     rthip_camera uploaded_{};
     bool have_cam_ = false;
 };

@@ -98,10 +98,21 @@ struct KernelParams {
     float *accum_out;    // optional caller copy (may be null)
     uint32_t *rgba8;     // optional, owned_rows*width (R | G<<8 | B<<16 | 255<<24)
     unsigned long long *stats;  // RT_STAT_* counters, RT_STAT_SHARDS shards of RT_STAT_N
+    // RTHIP_F_ADAPTIVE (lib.rs:276-313)
+    uint32_t *pix_state;          // per owned pixel: RT_PIX_* word (null: not adaptive)
+    const uint32_t *worklist;     // passes after the first: owned-pixel indices (lrow*width + x) still to trace (null: every pixel)
+    const uint32_t *worklist_count;
 };
+
+// per-pixel convergence state, the PixelCache fields of lib.rs:67-73 that the rule of lib.rs:300-311 needs
+#define RT_PIX_RGB_MASK 0x00ffffffu  /* last_color */
+#define RT_PIX_COUNT_SHIFT 24        /* same_color_count (<= 4) */
+#define RT_PIX_COUNT_MASK 0xfu
+#define RT_PIX_FINAL 0x40000000u     /* status == Final */
+#define RT_PIX_HAS_LAST 0x80000000u  /* last_color.is_some() */
 
 enum {
     RT_STAT_PATHS = 0, RT_STAT_RAYS = 1, RT_STAT_SPHERE = 2, RT_STAT_PLANE = 3, RT_STAT_TRI = 4, RT_STAT_NODE = 5,
-    RT_STAT_HIT0 = 6 /* +kind, 4 slots */, RT_STAT_SKY = 10, RT_STAT_SHADOW = 11, RT_STAT_N = 12
+    RT_STAT_HIT0 = 6 /* +kind, 4 slots */, RT_STAT_SKY = 10, RT_STAT_SHADOW = 11, RT_STAT_PIX_TRACED = 12, RT_STAT_PIX_FINAL = 13, RT_STAT_N = 14
 };
 #define RT_STAT_SHARDS 64

@@ -408,18 +408,29 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
         for (uint32_t i = threadIdx.x; i < 3 * P.n_spheres; i += 256) s_shade_mem[i] = P.sph_shade[i];
         __syncthreads();
     }
-    const uint32_t tiles_x = (P.width + 15u) >> 4;
-    const uint32_t tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t x = (tile_x << 4) + ((wave & 1u) << 3) + (lane & 7u);
-    const uint32_t lrow = (tile_y << 4) + ((wave >> 1) << 3) + (lane >> 3);
+    uint32_t x, lrow;
+    bool listed = true;
+    if (P.worklist) {
+        // RTHIP_F_ADAPTIVE, pass >= 2: thread i traces the i-th pixel that is not yet Final (compact_kernel)
+        const uint32_t gi = blockIdx.x * 256u + threadIdx.x;
+        listed = gi < *P.worklist_count;
+        const uint32_t oi = listed ? P.worklist[gi] : 0u;
+        lrow = oi / P.width;
+        x = oi - lrow * P.width;
+    } else {
+        const uint32_t tiles_x = (P.width + 15u) >> 4;
+        const uint32_t tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+        x = (tile_x << 4) + ((wave & 1u) << 3) + (lane & 7u);
+        lrow = (tile_y << 4) + ((wave >> 1) << 3) + (lane >> 3);
+    }
     // owned local row -> image row y (row bands interleaved over contexts)
     uint32_t y = lrow;
     if (P.band_rows) {
         uint32_t k = lrow / P.band_rows;
         y = (P.band_first + k * P.band_stride) * P.band_rows + (lrow - k * P.band_rows);
     }
-    const bool active = x < P.width && lrow < P.owned_rows && y < P.height;
+    const bool active = listed && x < P.width && lrow < P.owned_rows && y < P.height;
     const unsigned long long amask = __ballot(active);  // pixels of this wave's tile that exist
 
     uint32_t cnt[RT_STAT_N];
@@ -764,12 +775,23 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                 P.accum_out[oi * 3 + 1] = acc.y;
                 P.accum_out[oi * 3 + 2] = acc.z;
             }
-            if (P.rgba8) {
+            if (P.rgba8 || P.pix_state) {
                 // mean, clamp(0,1), sqrt, *255, `as u8` (truncate, saturate, NaN -> 0): lib.rs:294-299,30-38
                 float cr = __fsqrt_rn(fminf(fmaxf(acc.x * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
                 float cg = __fsqrt_rn(fminf(fmaxf(acc.y * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
                 float cb = __fsqrt_rn(fminf(fmaxf(acc.z * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
-                P.rgba8[oi] = uint32_t(cr) | (uint32_t(cg) << 8) | (uint32_t(cb) << 16) | 0xff000000u;
+                const uint32_t rgb = uint32_t(cr) | (uint32_t(cg) << 8) | (uint32_t(cb) << 16);
+                if (P.rgba8) P.rgba8[oi] = rgb | 0xff000000u;
+                if (P.pix_state) {
+                    // lib.rs:300-313: compare with last_color, count equal passes, Final after more than 3
+                    const uint32_t st = P.pix_state[oi];
+                    uint32_t count = (st >> RT_PIX_COUNT_SHIFT) & RT_PIX_COUNT_MASK;
+                    if (st & RT_PIX_HAS_LAST) count = ((st & RT_PIX_RGB_MASK) == rgb) ? count + 1u : 0u;
+                    const bool fin = count > 3u;  // MAX_SIMILAR_SAMPLE_FOR_A_PIXEL, lib.rs:244,309
+                    P.pix_state[oi] = rgb | (count << RT_PIX_COUNT_SHIFT) | (fin ? RT_PIX_FINAL : 0u) | RT_PIX_HAS_LAST;
+                    cnt[RT_STAT_PIX_TRACED]++;
+                    cnt[RT_STAT_PIX_FINAL] += fin ? 1u : 0u;
+                }
             }
         }
     }
@@ -777,12 +799,54 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
     // per-wave reduction of the counters, one atomic per wave and counter into a shard
 #pragma unroll
     for (int i = 0; i < RT_STAT_N; i++) {
-        if (!STATS && i > RT_STAT_RAYS) break;
+        if (!STATS && i > RT_STAT_RAYS && i < RT_STAT_PIX_TRACED) continue;
         uint32_t v = cnt[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if (lane == 0 && v) atomicAdd(&P.stats[(blockIdx.x & (RT_STAT_SHARDS - 1)) * RT_STAT_N + i], (unsigned long long)v);
     }
+}
+
+// RTHIP_F_ADAPTIVE, before every pass but the first: the work-list of the pixels that are not Final
+// (generate_pixel returns at once for a Final pixel, lib.rs:277-279). Thread i looks at the i-th
+// pixel in 8x8-tile order, so that 64 consecutive list entries stay a compact patch of the image
+// (coherent primary rays); a wave appends its survivors with one atomic. The order of the list
+// varies from run to run, the image does not: a pixel's samples depend on its index alone.
+// Final pixels get their stored colour written to the image outputs, which therefore need not
+// be the buffers of the previous pass.
+__global__ __launch_bounds__(256) void compact_kernel(const KernelParams P, uint32_t *list, uint32_t *count) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t tiles_x = (P.width + 7u) >> 3;
+    const uint32_t tile = i >> 6, in_tile = i & 63u;
+    const uint32_t x = (tile % tiles_x) * 8u + (in_tile & 7u), lrow = (tile / tiles_x) * 8u + (in_tile >> 3);
+    const bool inside = x < P.width && lrow < P.owned_rows;
+    const uint32_t oi = lrow * P.width + x;
+    const uint32_t st = inside ? P.pix_state[oi] : RT_PIX_FINAL;
+    const bool live = inside && !(st & RT_PIX_FINAL);
+    const unsigned long long mask = __ballot(live);
+    uint32_t base = 0;
+    if ((threadIdx.x & 63u) == 0 && mask) base = atomicAdd(count, uint32_t(__popcll(mask)));
+    base = __shfl(base, 0, 64);
+    if (live) list[base + __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u))] = oi;
+    if (inside && !live) {
+        if (P.rgba8) P.rgba8[oi] = (st & RT_PIX_RGB_MASK) | 0xff000000u;
+        if (P.accum_out) {
+            P.accum_out[size_t(oi) * 3 + 0] = P.accum[size_t(oi) * 3 + 0];
+            P.accum_out[size_t(oi) * 3 + 1] = P.accum[size_t(oi) * 3 + 1];
+            P.accum_out[size_t(oi) * 3 + 2] = P.accum[size_t(oi) * 3 + 2];
+        }
+    }
+    const unsigned long long fmask = __ballot(inside && !live);
+    if ((threadIdx.x & 63u) == 0 && fmask)
+        atomicAdd(&P.stats[(blockIdx.x & (RT_STAT_SHARDS - 1)) * RT_STAT_N + RT_STAT_PIX_FINAL], (unsigned long long)__popcll(fmask));
+}
+
+extern "C" hipError_t rt_launch_compact(const KernelParams *P, uint32_t *list, uint32_t *count, hipStream_t stream) {
+    const uint32_t tiles = ((P->width + 7u) >> 3) * ((P->owned_rows + 7u) >> 3);
+    const uint32_t blocks = (tiles + 3u) / 4u;  // 4 tiles of 64 pixels per block
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(256), 0, stream, *P, list, count);
+    return hipGetLastError();
 }
 
 // Raytracer::get_shape — lib.rs:262-267: one un-jittered primary ray, index of the closest shape.
@@ -830,7 +894,8 @@ static uint32_t default_chunk() {
 extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats, hipStream_t stream) {
     KernelParams P = *Pin;
     const uint32_t tiles_x = (P.width + 15u) >> 4, tiles_y = (P.owned_rows + 15u) >> 4;
-    const uint32_t blocks = tiles_x * tiles_y;
+    uint32_t blocks = tiles_x * tiles_y;
+    if (P.worklist) blocks = uint32_t((uint64_t(P.owned_rows) * P.width + 255u) / 256u);  // worst case: nothing is Final yet
     if (blocks == 0 || P.spp == 0) return hipSuccess;
     const bool lights = (P.flags & RTHIP_F_POINT_LIGHTS) && P.n_lights > 0;
     const int mode = P.n_bvh_nodes > 0 ? MODE_BVH : (P.n_spheres <= RT_LDS_SPHERES ? MODE_LDS : MODE_GLOBAL);

@@ -16,6 +16,7 @@
 #include "rt_device.h"
 
 extern "C" hipError_t rt_launch_render(const KernelParams *P, int count_stats, hipStream_t stream);
+extern "C" hipError_t rt_launch_compact(const KernelParams *P, uint32_t *list, uint32_t *count, hipStream_t stream);
 extern "C" hipError_t rt_launch_pick(const KernelParams *P, float u, float v, long long *d_out, hipStream_t stream);
 
 namespace {
@@ -36,12 +37,13 @@ struct rthip_ctx {
     int device = 0;
     std::string err;
     DevBuf sph_geom, sph_shade, pln_geom, tri_geom, materials, texels, tex_info, lights, bvh_nodes, bvh_recs;
-    DevBuf stats, accum, staging_rgba, staging_accum, pick_out;
+    DevBuf stats, accum, staging_rgba, staging_accum, pick_out, pix_state, worklist;
     KernelParams base;
     bool have_scene = false, have_camera = false;
     rthip_camera camera;
     // running-sum state (lib.rs:67-73)
     uint64_t nb_samples = 0;
+    bool adaptive = false;  // the running sum was built by RTHIP_F_ADAPTIVE passes (pix_state is live)
     uint32_t acc_width = 0, acc_height = 0, acc_rows = 0, acc_band_rows = 0, acc_band_first = 0, acc_band_stride = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t stream = nullptr;  // used by the synchronous entry points
@@ -130,7 +132,7 @@ int validate_params(rthip_ctx *ctx, const rthip_render_params *p) {
     if (p->width > 65536 || p->height > 65536) return fail(ctx, RTHIP_E_BADARG, "width/height above 65536 are not supported");
     if (p->spp == 0) return fail(ctx, RTHIP_E_BADARG, "spp must be >= 1");
     if (p->band_rows != 0 && p->band_stride == 0) return fail(ctx, RTHIP_E_BADARG, "band_stride must be >= 1 when band_rows != 0");
-    if (p->flags & ~uint32_t(RTHIP_F_ACCUMULATE | RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_NO_BVH))
+    if (p->flags & ~uint32_t(RTHIP_F_ACCUMULATE | RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_NO_BVH | RTHIP_F_ADAPTIVE))
         return fail(ctx, RTHIP_E_BADARG, "unknown flag bits");
     for (int i = 0; i < 7; i++)
         if (p->reserved[i] != 0) return fail(ctx, RTHIP_E_BADARG, "reserved fields must be 0");
@@ -247,7 +249,7 @@ void rthip_destroy(rthip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->sph_geom, &ctx->sph_shade, &ctx->pln_geom, &ctx->tri_geom, &ctx->materials, &ctx->texels, &ctx->tex_info, &ctx->lights,
-                      &ctx->bvh_nodes, &ctx->bvh_recs, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out})
+                      &ctx->bvh_nodes, &ctx->bvh_recs, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out, &ctx->pix_state, &ctx->worklist})
         b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -455,6 +457,28 @@ int rthip_reset_accum(rthip_ctx *ctx) {
     return RTHIP_OK;
 }
 
+int rthip_pixel_status(rthip_ctx *ctx, uint8_t *status_out, uint8_t *same_color_count_out) {
+    if (!ctx) return RTHIP_E_BADARG;
+    if (!status_out) return fail(ctx, RTHIP_E_BADARG, "status_out is NULL");
+    if (!ctx->adaptive || ctx->nb_samples == 0) return fail(ctx, RTHIP_E_STATE, "no RTHIP_F_ADAPTIVE pass has run since the last reset");
+    try {
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        const size_t npx = size_t(ctx->acc_rows) * ctx->acc_width;
+        std::vector<uint32_t> st(npx);
+        HIPCHK(ctx, hipDeviceSynchronize());
+        HIPCHK(ctx, hipMemcpy(st.data(), ctx->pix_state.p, npx * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < npx; i++) {
+            status_out[i] = (st[i] & RT_PIX_FINAL) ? RTHIP_STATUS_FINAL : ((st[i] & RT_PIX_HAS_LAST) ? RTHIP_STATUS_UNSTABLE : RTHIP_STATUS_NOT_STARTED);
+            if (same_color_count_out) same_color_count_out[i] = uint8_t((st[i] >> RT_PIX_COUNT_SHIFT) & RT_PIX_COUNT_MASK);
+        }
+        return RTHIP_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, RTHIP_E_OOM, "host allocation failed in rthip_pixel_status");
+    } catch (...) {
+        return fail(ctx, RTHIP_E_INTERNAL, "unexpected exception in rthip_pixel_status");
+    }
+}
+
 int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgba8, void *d_accum, void *hip_stream, rthip_stats *stats) {
     if (!ctx) return RTHIP_E_BADARG;
     try {
@@ -471,6 +495,9 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rg
                                  ctx->acc_band_rows == p->band_rows && ctx->acc_band_first == p->band_first && ctx->acc_band_stride == p->band_stride;
         const bool accumulate = (p->flags & RTHIP_F_ACCUMULATE) && ctx->nb_samples > 0;
         if (accumulate && !same_layout) return fail(ctx, RTHIP_E_STATE, "RTHIP_F_ACCUMULATE with a different image/band layout than the running sum");
+        const bool adaptive = (p->flags & RTHIP_F_ADAPTIVE) != 0;
+        if (accumulate && adaptive != ctx->adaptive)
+            return fail(ctx, RTHIP_E_STATE, "RTHIP_F_ADAPTIVE must be set on every pass of a running sum or on none (Final pixels stop accumulating)");
         const uint64_t prior = accumulate ? ctx->nb_samples : 0;
         if (prior + p->spp > 0xffffffffull) return fail(ctx, RTHIP_E_BADARG, "more than 2^32 samples per pixel");
         if (rows == 0) {
@@ -497,12 +524,28 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rg
 
         HIPCHK(ctx, hipMemsetAsync(ctx->stats.p, 0, ctx->stats.bytes, stream));
         if (stats) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
+        if (adaptive) {
+            const size_t npx = size_t(rows) * p->width;
+            if ((st = ensure(ctx, ctx->pix_state, npx * sizeof(uint32_t)))) return st;
+            if ((st = ensure(ctx, ctx->worklist, (npx + 1) * sizeof(uint32_t)))) return st;
+            k.pix_state = (uint32_t *)ctx->pix_state.p;
+            if (!accumulate) {
+                // first pass: every PixelCache starts NotStarted (lib.rs:120-138)
+                HIPCHK(ctx, hipMemsetAsync(ctx->pix_state.p, 0, npx * sizeof(uint32_t), stream));
+            } else {
+                uint32_t *count = (uint32_t *)ctx->worklist.p, *list = count + 1;
+                HIPCHK(ctx, hipMemsetAsync(count, 0, sizeof(uint32_t), stream));
+                HIPCHK(ctx, rt_launch_compact(&k, list, count, stream));
+                k.worklist = list, k.worklist_count = count;
+            }
+        }
         HIPCHK(ctx, rt_launch_render(&k, (p->flags & RTHIP_F_COUNT_STATS) ? 1 : 0, stream));
         if (stats) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
 
         ctx->acc_width = p->width, ctx->acc_height = p->height, ctx->acc_rows = rows;
         ctx->acc_band_rows = p->band_rows, ctx->acc_band_first = p->band_first, ctx->acc_band_stride = p->band_stride;
         ctx->nb_samples = prior + p->spp;
+        ctx->adaptive = adaptive;
 
         if (stats) {
             std::memset(stats, 0, sizeof *stats);
@@ -521,7 +564,10 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rg
                 for (int k = 0; k < 4; k++) stats->hits[k] += h[sh * RT_STAT_N + RT_STAT_HIT0 + k];
                 stats->sky_evals += h[sh * RT_STAT_N + RT_STAT_SKY];
                 stats->shadow_rays += h[sh * RT_STAT_N + RT_STAT_SHADOW];
+                stats->pixels_traced += h[sh * RT_STAT_N + RT_STAT_PIX_TRACED];
+                stats->pixels_final += h[sh * RT_STAT_N + RT_STAT_PIX_FINAL];
             }
+            if (!adaptive) stats->pixels_traced = uint64_t(rows) * p->width;
             stats->rows = rows;
             stats->nb_samples = ctx->nb_samples;
             stats->kernel_ms = ms;

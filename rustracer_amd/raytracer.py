@@ -144,11 +144,13 @@ class Raytracer:
 
     # ---- the batch form of generate_pixel ----
     def render(self, scene, samples, renderer: Optional[PixelRenderer] = None, max_depth=50, accumulate=False, flags=0,
-               want_accum=True, band_rows=0, band_first=0, band_stride=1, lights=()) -> RenderResult:
+               want_accum=True, band_rows=0, band_first=0, band_stride=1, lights=(), adaptive=False) -> RenderResult:
+        """adaptive: the convergence rule of lib.rs:276-313 — Final pixels are skipped by later (accumulate=True) passes."""
         self._sync_scene_camera(scene, lights)
-        fl = flags | (abi.F_ACCUMULATE if accumulate else 0)
+        fl = flags | (abi.F_ACCUMULATE if accumulate else 0) | (abi.F_ADAPTIVE if adaptive else 0)
         p = make_params(int(self.width), int(self.height), samples, max_depth, self.seed, fl, band_rows, band_first, band_stride)
         rows = owned_rows(p)
+        self._last_rows = rows
         w = int(self.width)
         rgba = np.empty((rows, w, 4), np.uint8)
         acc = np.empty((rows, w, 3), np.float32) if want_accum else None
@@ -165,6 +167,17 @@ class Raytracer:
         _check(self._lib.rthip_render_device(self._ctx, C.byref(params), d_rgba8 or None, d_accum or None, stream or None,
                                              C.byref(st) if want_stats else None), self._ctx)
         return st.as_dict() if want_stats else None
+
+    def pixel_status(self):
+        """PixelColor.status / PixelCache.same_color_count of every owned pixel after the last adaptive pass (lib.rs:59-73)."""
+        p = make_params(int(self.width), int(self.height), 1, 1, 0)
+        n = C.c_uint32(0)
+        # the layout of the last pass is the context's; the full image unless bands were used
+        rows = self._last_rows if getattr(self, "_last_rows", None) else int(self.height)
+        status = np.empty((rows, int(self.width)), np.uint8)
+        count = np.empty((rows, int(self.width)), np.uint8)
+        _check(self._lib.rthip_pixel_status(self._ctx, status.ctypes.data, count.ctypes.data), self._ctx)
+        return status, count
 
     def invalidate_pixels(self):
         _check(self._lib.rthip_reset_accum(self._ctx), self._ctx)

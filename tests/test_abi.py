@@ -29,7 +29,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(abi.Material) == 48 and C.sizeof(abi.Sphere) == 40 and C.sizeof(abi.Plane) == 56
     assert C.sizeof(abi.Triangle) == 80 and C.sizeof(abi.Light) == 48 and C.sizeof(abi.Texture) == 16
     assert C.sizeof(abi.SceneDesc) == 96 and C.sizeof(abi.Camera) == 96 and C.sizeof(abi.RenderParams) == 64
-    assert C.sizeof(abi.Stats) == 8 * 14 + 16
+    assert C.sizeof(abi.Stats) == 8 * 14 + 16 + 16  # ABI v2: + pixels_traced, pixels_final
 
 
 def test_camera_lookat_matches_oracle(oracle_mod):

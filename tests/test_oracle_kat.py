@@ -222,3 +222,28 @@ def test_generate_pixel_accumulation_contract(oracle_mod, standalone_flat, defau
     assert np.allclose(sum_b, sum4, rtol=1e-12, atol=1e-12)
     assert np.abs(rgba_b.astype(int) - rgba4.astype(int)).max() <= 1
     assert st4["paths"] == w * h * 4 and st4["rays"] >= st4["paths"] * 0 and st4["rays"] <= st4["paths"] * 50
+
+
+def test_adaptive_rule_in_the_oracle(oracle_mod, default_camera, standalone_flat):
+    """lib.rs:276-313 in the oracle's PixelCache against an independent state machine over its own per-pass colours;
+    a Final pixel stops sampling (nb_samples frozen, lib.rs:277-279,293)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from adaptive_rule import FINAL, RuleEmulator
+    from rustracer_amd import abi, make_params
+    w, h, spp, depth, seed = 96, 54, 1, 50, 2
+    state = oracle_mod.AdaptiveState(w, h)
+    emu = RuleEmulator(h, w)
+    for k in range(12):
+        live = emu.live()
+        p = make_params(w, h, spp, depth, seed, abi.F_ADAPTIVE | (abi.F_ACCUMULATE if k else 0))
+        st = oracle_mod.render_adaptive(standalone_flat, default_camera, p, state)
+        emu.step(state.rgba[..., :3])
+        assert np.array_equal(state.status, emu.status)
+        assert np.array_equal(state.same_color_count, emu.count)
+        assert st["pixels_traced"] == int(live.sum()) and st["paths"] == int(live.sum()) * spp
+        assert st["pixels_final"] == int((emu.status == FINAL).sum())
+        assert np.array_equal(state.nb_samples[emu.live()], np.full(int(emu.live().sum()), (k + 1) * spp, np.uint64))
+    assert (emu.status == FINAL).any() and emu.live().any()
+    froze_at = state.nb_samples[emu.status == FINAL]
+    assert froze_at.min() >= 5 * spp and froze_at.max() <= 12 * spp
