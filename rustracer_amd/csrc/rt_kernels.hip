@@ -167,8 +167,11 @@ __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
     s.ref = 0;  // the root is always an inner node
     s.sp = 0;
 }
+#ifndef RT_BVH_LEAF_LANES
+#define RT_BVH_LEAF_LANES 28
+#endif
 #ifndef RT_BVH_YIELD_LANES
-#define RT_BVH_YIELD_LANES 16
+#define RT_BVH_YIELD_LANES 24
 #endif
 // Runs the traversal of every calling lane. YIELD: returns early (s.ref != RT_BVH_DONE on the
 // unfinished lanes) once RT_BVH_YIELD_LANES lanes of the wave have finished, so that the caller can
@@ -182,7 +185,10 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
     int sp = s.sp;
     bool found = false;
     for (;;) {
-        while (ref < RT_BVH_DONE) {  // inner node
+        // inner nodes: every lane walks down until RT_BVH_LEAF_LANES lanes of the wave wait at a leaf (waiting for
+        // the LAST lane to reach one leaves three quarters of the wave idle: the walk lengths are heavy-tailed)
+        while (__ballot(ref < RT_BVH_DONE) != 0ull) {
+          if (ref < RT_BVH_DONE) {
             const rt_f4 q0 = nodes[4 * ref], q1 = nodes[4 * ref + 1], q2 = nodes[4 * ref + 2], q3 = nodes[4 * ref + 3];
             if (STATS) cnt[RT_STAT_NODE] += 2;
             const float limit = ANY ? r.tmax : fminf(h.t, r.tmax);
@@ -203,8 +209,10 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
             } else {
                 ref = RT_BVH_DONE;
             }
+          }
+          if (__popcll(__ballot(ref > RT_BVH_DONE)) >= RT_BVH_LEAF_LANES) break;
         }
-        if (ref != RT_BVH_DONE) {  // leaf
+        if (ref > RT_BVH_DONE) {  // leaf
             const uint32_t first = (ref & ~RT_BVH_LEAF_BIT) >> 2, count = (ref & 3u) + 1u;
             for (uint32_t k = 0; k < count; k++) {
                 const rt_f4 *rec = P.bvh_recs + 3 * size_t(first + k);
