@@ -174,7 +174,7 @@ def cpu_baseline(flat):
     from rustracer_amd import make_params
     cam = oracle.camera_lookat(-1.8, 1.0, 2.0)
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, oracle.hw_threads())
-    spp1, sppn = 8, 8 * threads
+    spp1, sppn = 16, 16 * threads  # ~10 s each on the GPU box's host cores
     p1 = make_params(WIDTH, HEIGHT, spp1, MAX_DEPTH, 1)
     _, _, st1, s1 = oracle.render(flat, cam, p1, precision=64, threads=1)
     pn = make_params(WIDTH, HEIGHT, sppn, MAX_DEPTH, 1)
