@@ -3,6 +3,8 @@
 // on the GPU through a PixelRenderer (the `World` framebuffer of standalone/src/renderers/pixels.rs:205-262,
 // reduced to a byte buffer), writes a PPM and prints one JSON line of statistics.
 //   rthip_cli [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--texture path.rgb8.z] [--out image.ppm]
+//             [--passes P]   P > 0: the standalone window's progressive loop (standalone/src/main.rs:99-102) — P adaptive
+//                            passes of N samples with the convergence rule of lib.rs:276-313 instead of one batch
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,18 +17,19 @@ using namespace raytracer_hip;
 struct World : PixelRenderer {  // standalone/src/renderers/pixels.rs:205-262
     uint32_t width, height;
     std::vector<uint8_t> pixels;  // y-up RGBA8
-    uint64_t writes = 0;
+    uint64_t writes = 0, final_writes = 0;
     World(uint32_t w, uint32_t h) : width(w), height(h), pixels(size_t(w) * h * 4, 0) {}
     void set_pixel(PixelPosition pos, PixelColor c) override {
         uint8_t *p = &pixels[(pos.y * width + pos.x) * 4];
         p[0] = c.r, p[1] = c.g, p[2] = c.b, p[3] = 255;
         writes++;
+        if (c.status == GenerationStatus::Final) final_writes++;
     }
     void invalidate_pixels() override { std::fill(pixels.begin(), pixels.end(), 0); }
 };
 
 int main(int argc, char **argv) {
-    uint32_t width = 960, height = 540, spp = 16, depth = 50, seed = 1;  // standalone/src/main.rs:51-52, ray.rs:44
+    uint32_t width = 960, height = 540, spp = 16, depth = 50, seed = 1, passes = 0;  // standalone/src/main.rs:51-52, ray.rs:44
     std::string out, texture = "tests/golden/textures/bergsjostolen.rgb8.z";
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i];
@@ -35,6 +38,7 @@ int main(int argc, char **argv) {
         else if (k == "--spp") spp = std::atoi(argv[i + 1]);
         else if (k == "--depth") depth = std::atoi(argv[i + 1]);
         else if (k == "--seed") seed = std::atoi(argv[i + 1]);
+        else if (k == "--passes") passes = std::atoi(argv[i + 1]);
         else if (k == "--texture") texture = argv[i + 1];
         else if (k == "--out") out = argv[i + 1];
         else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
@@ -50,13 +54,27 @@ int main(int argc, char **argv) {
         HipRaytracer rt(width, height, seed);
         rt.upload(desc);
         World world(width, height);
-        rthip_stats st = rt.render(spp, depth, &world);
+        rthip_stats st{};
+        uint64_t paths = 0, rays = 0, final_pixels = 0;
+        double kernel_ms = 0.0;
+        if (passes == 0) {
+            st = rt.render(spp, depth, &world);
+            paths = st.paths, rays = st.rays, kernel_ms = st.kernel_ms;
+        } else {
+            for (uint32_t k = 0; k < passes; k++) {
+                st = rt.render_adaptive_pass(spp, depth, &world, k == 0);
+                paths += st.paths, rays += st.rays, kernel_ms += st.kernel_ms;
+            }
+            final_pixels = st.pixels_final;
+        }
         int64_t centre = rt.get_shape((width - 1) * 0.5, (height - 1) * 0.5);
         if (!out.empty()) write_ppm_p3(out, world.pixels, width, height);
         std::printf("{\"width\": %u, \"height\": %u, \"spp\": %u, \"max_depth\": %u, \"paths\": %llu, \"rays\": %llu, \"kernel_ms\": %.3f, "
-                    "\"d2h_ms\": %.3f, \"mrays_per_s\": %.1f, \"set_pixel_calls\": %llu, \"shape_at_centre\": %lld}\n",
-                    width, height, spp, depth, (unsigned long long)st.paths, (unsigned long long)st.rays, st.kernel_ms, st.d2h_ms,
-                    st.rays / st.kernel_ms / 1e3, (unsigned long long)world.writes, (long long)centre);
+                    "\"d2h_ms\": %.3f, \"mrays_per_s\": %.1f, \"set_pixel_calls\": %llu, \"shape_at_centre\": %lld, \"passes\": %u, "
+                    "\"final_pixels\": %llu, \"final_set_pixel_calls\": %llu}\n",
+                    width, height, spp, depth, (unsigned long long)paths, (unsigned long long)rays, kernel_ms, st.d2h_ms,
+                    rays / kernel_ms / 1e3, (unsigned long long)world.writes, (long long)centre, passes, (unsigned long long)final_pixels,
+                    (unsigned long long)world.final_writes);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "rthip_cli: %s\n", e.what());
         return 1;

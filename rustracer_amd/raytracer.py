@@ -170,8 +170,6 @@ class Raytracer:
 
     def pixel_status(self):
         """PixelColor.status / PixelCache.same_color_count of every owned pixel after the last adaptive pass (lib.rs:59-73)."""
-        p = make_params(int(self.width), int(self.height), 1, 1, 0)
-        n = C.c_uint32(0)
         # the layout of the last pass is the context's; the full image unless bands were used
         rows = self._last_rows if getattr(self, "_last_rows", None) else int(self.height)
         status = np.empty((rows, int(self.width)), np.uint8)

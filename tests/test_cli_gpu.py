@@ -32,3 +32,26 @@ def test_cli_matches_python_layer(tmp_path):
     assert info["rays"] == res.stats["rays"]
     assert np.array_equal(ppm, res.rgba8[::-1, :, :3])  # the PPM is written top row first
     rt.close()
+
+
+def test_cli_progressive_adaptive_passes(tmp_path):
+    """--passes: the standalone window's loop with the reference's convergence rule; set_pixel only for pixels that were not
+    Final before a pass, each Final pixel reported as Final exactly once (lib.rs:277-279,309-314)"""
+    w, h, passes, depth, seed = 160, 90, 10, 50, 4
+    out = tmp_path / "img.ppm"
+    r = subprocess.run([CLI, "--width", str(w), "--height", str(h), "--spp", "1", "--depth", str(depth), "--seed", str(seed), "--passes", str(passes),
+                        "--texture", presets.texture_path("bergsjostolen"), "--out", str(out)], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout)
+    rt = Raytracer.new(w, h, seed=seed)
+    paths = 0
+    scene = presets.standalone_scene()   # one object: a new scene would be re-uploaded, which invalidates the running sum
+    for k in range(passes):
+        res = rt.render(scene, 1, max_depth=depth, accumulate=k > 0, adaptive=True)
+        paths += res.stats["paths"]
+    assert info["paths"] == paths == info["set_pixel_calls"]   # spp = 1: one set_pixel per traced pixel
+    assert info["final_pixels"] == res.stats["pixels_final"] == info["final_set_pixel_calls"] > 0
+    tok = out.read_text().split()
+    ppm = np.array(tok[4:], dtype=np.uint8).reshape(h, w, 3)
+    assert np.array_equal(ppm, res.rgba8[::-1, :, :3])
+    rt.close()

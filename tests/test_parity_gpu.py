@@ -321,3 +321,31 @@ def test_full_size_4k_properties(standalone_flat):
     want = (np.sqrt(mean.astype(np.float32)) * np.float32(255.0)).astype(np.uint8)
     assert np.abs(want.astype(int) - whole.rgba8[..., :3].astype(int)).max() <= 1
     rt.close()
+
+
+def test_full_size_8k_bvh_properties():
+    """C5 at its full size: 7680x4320, 10 001 spheres + an 81 920-triangle mesh through the BVH, work pool and
+    leaf-ordered records. Size-independent properties: counter identities, 8-way band split == whole frame (checksum of
+    checksums), determinism, and BVH == brute force on a band the linear scan can afford."""
+    import zlib
+    w, h, spp, depth = 7680, 4320, 1, 8
+    flat = flatten(presets.big_scene(100, 7, mesh_subdivisions=6))
+    rt = Raytracer.new(w, h, seed=5)
+    whole = rt.render(flat, spp, max_depth=depth, flags=abi.F_COUNT_STATS, want_accum=False)
+    s = whole.stats
+    assert s["paths"] == w * h * spp and s["paths"] <= s["rays"] <= s["paths"] * depth
+    assert s["node_tests"] > 0 and s["node_tests"] % 2 == 0 and s["tri_tests"] > 0
+    assert sum(s["hits"]) + s["sky_evals"] >= s["rays"]
+    again = rt.render(flat, spp, max_depth=depth, want_accum=False)
+    assert zlib.crc32(again.rgba8.tobytes()) == zlib.crc32(whole.rgba8.tobytes())
+    full = np.empty_like(whole.rgba8)
+    for rank in range(8):
+        part = rt.render(flat, spp, max_depth=depth, band_rows=8, band_first=rank, band_stride=8, want_accum=False)
+        full[owned_row_indices(h, 8, rank, 8)] = part.rgba8
+    assert zlib.crc32(full.tobytes()) == zlib.crc32(whole.rgba8.tobytes())
+    # one band of 8 rows through the middle of the image (61 440 pixels x 10 001 + 81 920 tests) by the linear scan of ray.rs:47-67
+    mid = (h // 2) // 8
+    nbands = h // 8
+    brute = rt.render(flat, spp, max_depth=depth, flags=abi.F_NO_BVH, band_rows=8, band_first=mid, band_stride=nbands, want_accum=False)
+    assert np.array_equal(brute.rgba8, whole.rgba8[mid * 8:(mid + 1) * 8])
+    rt.close()
