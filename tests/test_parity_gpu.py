@@ -349,3 +349,22 @@ def test_full_size_8k_bvh_properties():
     brute = rt.render(flat, spp, max_depth=depth, flags=abi.F_NO_BVH, band_rows=8, band_first=mid, band_stride=nbands, want_accum=False)
     assert np.array_equal(brute.rgba8, whole.rgba8[mid * 8:(mid + 1) * 8])
     rt.close()
+
+
+def test_bvh_point_lights_and_planes(oracle_mod, default_camera):
+    """the extensions together: shadow-ray any-hit through the BVH (the shading lane's own, empty, stack column), an
+    unbounded plane outside the tree, triangles with a textured material — BVH == linear scan bit for bit, and vs the oracle"""
+    from rustracer_amd import Plane, PointLight
+    shapes = presets.mesh_scene(5, 2) + [Plane.new((0.0, -0.45, 0.0), (0.0, 1.0, 0.0), Lambertian.new((0.6, 0.6, 0.2)))]
+    flat = flatten(shapes, [PointLight((4.0, 5.0, 2.0), (30.0, 30.0, 30.0)), PointLight((-3.0, 2.0, 1.0), (6.0, 4.0, 2.0))])
+    w, h, spp, depth = 256, 144, 3, 4
+    rt = Raytracer.new(w, h, seed=23)
+    a = rt.render(flat, spp, max_depth=depth, flags=abi.F_POINT_LIGHTS | abi.F_COUNT_STATS)
+    b = rt.render(flat, spp, max_depth=depth, flags=abi.F_POINT_LIGHTS | abi.F_COUNT_STATS | abi.F_NO_BVH)
+    assert a.stats["node_tests"] > 0 and b.stats["node_tests"] == 0 and a.stats["shadow_rays"] > 0
+    assert np.array_equal(a.accum, b.accum) and a.stats["rays"] == b.stats["rays"] and a.stats["shadow_rays"] == b.stats["shadow_rays"]
+    ref, _, st, _ = oracle_mod.render(flat, default_camera, make_params(w, h, spp, depth, 23, abi.F_POINT_LIGHTS), precision=64)
+    hist, ok = assert_parity(a.rgba8, ref, "BVH + planes + point lights vs oracle f64")
+    print(f"\nbvh+lights+plane: {describe(hist, ok)}; shadow rays device {a.stats['shadow_rays']} oracle {st['shadow_rays']}")
+    assert abs(a.stats["shadow_rays"] - st["shadow_rays"]) <= 5e-3 * st["shadow_rays"]
+    rt.close()
