@@ -31,31 +31,57 @@ def max_owned_rows(height: int, band_rows: int, world: int) -> int:
     return max(len(owned_row_indices(height, band_rows, r, world)) for r in range(world))
 
 
+class RowGatherer:
+    """The framebuffer exchange of one (height, band_rows, world) layout with everything that does not change
+    between frames built once: the receive buffer of `dst` and ONE destination-row index that de-interleaves all
+    ranks' rows with a single index_copy (padding rows of the shorter ranks land in scratch rows past the image),
+    so a frame costs one collective + one copy kernel and no host->device transfer."""
+
+    def __init__(self, height: int, band_rows: int, rank: int, world: int, trailing_shape, dtype, device, dst: int = 0):
+        import torch
+
+        self.height, self.band_rows, self.rank, self.world, self.dst = height, band_rows, rank, world, dst
+        self.pad_rows = max_owned_rows(height, band_rows, world)
+        self.trailing, self.dtype, self.device = tuple(trailing_shape), dtype, device
+        self.own_rows = len(owned_row_indices(height, band_rows, rank, world))
+        self.padded = None if self.own_rows == self.pad_rows else torch.zeros((self.pad_rows,) + self.trailing, dtype=dtype, device=device)
+        if rank == dst:
+            self.recv = torch.empty((world, self.pad_rows) + self.trailing, dtype=dtype, device=device)
+            self.parts = [self.recv[r] for r in range(world)]
+            index = np.empty(world * self.pad_rows, np.int64)
+            scratch = height
+            for r in range(world):
+                idx = owned_row_indices(height, band_rows, r, world)
+                index[r * self.pad_rows: r * self.pad_rows + len(idx)] = idx
+                n_pad = self.pad_rows - len(idx)
+                index[r * self.pad_rows + len(idx): (r + 1) * self.pad_rows] = np.arange(scratch, scratch + n_pad)
+                scratch += n_pad
+            self.n_scratch = scratch - height
+            self.index = torch.from_numpy(index).to(device)
+            self.full = torch.empty((height + self.n_scratch,) + self.trailing, dtype=dtype, device=device)
+
+    def __call__(self, local, group=None):
+        import torch.distributed as dist
+
+        if self.padded is not None:
+            self.padded[: self.own_rows].copy_(local)
+            send = self.padded
+        else:
+            send = local.contiguous()
+        if self.rank == self.dst:
+            dist.gather(send, gather_list=self.parts, dst=self.dst, group=group)
+            self.full.index_copy_(0, self.index, self.recv.view((self.world * self.pad_rows,) + self.trailing))
+            return self.full[: self.height]
+        dist.gather(send, gather_list=None, dst=self.dst, group=group)
+        return None
+
+
 def gather_rows(local, height: int, band_rows: int, rank: int, world: int, group=None, dst: int = 0):
     """Gather every rank's owned rows (tensor (rows_r, ...), same trailing shape and dtype on all ranks)
-    to `dst` and return the de-interleaved (height, ...) tensor there (None elsewhere)."""
-    import torch
-    import torch.distributed as dist
-
+    to `dst` and return the de-interleaved (height, ...) tensor there (None elsewhere). One-shot form of RowGatherer."""
     if world == 1:
         return local
-    pad_rows = max_owned_rows(height, band_rows, world)
-    if local.shape[0] != pad_rows:
-        padded = torch.zeros((pad_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        padded[: local.shape[0]] = local
-    else:
-        padded = local.contiguous()
-    if rank == dst:
-        parts = [torch.empty_like(padded) for _ in range(world)]
-        dist.gather(padded, gather_list=parts, dst=dst, group=group)
-        full = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        for r in range(world):
-            idx = owned_row_indices(height, band_rows, r, world)
-            if len(idx):
-                full.index_copy_(0, torch.from_numpy(idx).to(local.device), parts[r][: len(idx)])
-        return full
-    dist.gather(padded, gather_list=None, dst=dst, group=group)
-    return None
+    return RowGatherer(height, band_rows, rank, world, local.shape[1:], local.dtype, local.device, dst)(local, group)
 
 
 class BandRenderer:
@@ -75,6 +101,7 @@ class BandRenderer:
         assert self.rows == len(owned_row_indices(self.height, band_rows if world > 1 else 0, rank, world))
         dev = torch.device("cuda", torch.cuda.current_device())
         self.rgba = torch.empty((self.rows, self.width, 4), dtype=torch.uint8, device=dev)
+        self._gatherer = None if world == 1 else RowGatherer(self.height, band_rows, rank, world, (self.width, 4), torch.uint8, dev)
 
     def params(self, spp, max_depth, flags, seed=None):
         if self.world == 1:
@@ -88,4 +115,5 @@ class BandRenderer:
         return self.rt.render_device(self.params(spp, max_depth, flags, seed), self.rgba.data_ptr(), 0, stream, want_stats)
 
     def gather(self, group=None):
-        return gather_rows(self.rgba, self.height, self.band_rows, self.rank, self.world, group)
+        """the frame on rank 0 (a view of a buffer that the next gather overwrites), None elsewhere"""
+        return self.rgba if self._gatherer is None else self._gatherer(self.rgba, group)

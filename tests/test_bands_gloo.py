@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from rustracer_amd.bands import gather_rows, max_owned_rows, owned_row_indices  # noqa: E402
+from rustracer_amd.bands import RowGatherer, gather_rows, max_owned_rows, owned_row_indices  # noqa: E402
 
 
 def _free_port():
@@ -45,6 +45,14 @@ def _worker(rank, world, port, cases, out_path):
             ok &= bool((full[:, :, 3] == 255).all())
         else:
             ok &= full is None
+        # the per-frame form bench.py uses: buffers and the de-interleave index built once, reused for every frame
+        g = RowGatherer(h, band_rows, rank, world, (w, 4), torch.uint8, torch.device("cpu"))
+        for frame in range(3):
+            again = g(local + frame)   # uint8 wrap-around is fine: the expected value wraps the same way
+            if rank == 0:
+                ok &= again.shape == (h, w, 4) and bool((again == full + frame).all())
+            else:
+                ok &= again is None
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
