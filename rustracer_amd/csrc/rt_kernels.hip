@@ -188,6 +188,13 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
         // inner nodes: every lane walks down until RT_BVH_LEAF_LANES lanes of the wave wait at a leaf (waiting for
         // the LAST lane to reach one leaves three quarters of the wave idle: the walk lengths are heavy-tailed)
         while (__ballot(ref < RT_BVH_DONE) != 0ull) {
+#ifdef RT_BVH_DEBUG_UTIL
+          if (STATS) {
+              const unsigned long long ex = __ballot(true);
+              if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex), 0u)) == 0) cnt[RT_STAT_SKY] += 64;
+              if (ref < RT_BVH_DONE) cnt[RT_STAT_SHADOW]++;
+          }
+#endif
           if (ref < RT_BVH_DONE) {
             const rt_f4 q0 = nodes[4 * ref], q1 = nodes[4 * ref + 1], q2 = nodes[4 * ref + 2], q3 = nodes[4 * ref + 3];
             if (STATS) cnt[RT_STAT_NODE] += 2;
@@ -215,6 +222,13 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
         if (ref > RT_BVH_DONE) {  // leaf
             const uint32_t first = (ref & ~RT_BVH_LEAF_BIT) >> 2, count = (ref & 3u) + 1u;
             for (uint32_t k = 0; k < count; k++) {
+#ifdef RT_BVH_DEBUG_UTIL
+                if (STATS) {
+                    const unsigned long long ex = __ballot(true);
+                    if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex), 0u)) == 0) cnt[RT_STAT_HIT0] += 64;
+                    cnt[RT_STAT_HIT0 + 1]++;
+                }
+#endif
                 const rt_f4 *rec = P.bvh_recs + 3 * size_t(first + k);
                 const rt_f4 a = rec[0], b = rec[1], c = rec[2];
                 const uint32_t id = __float_as_uint(a.w);
