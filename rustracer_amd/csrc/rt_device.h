@@ -17,6 +17,10 @@
 
 #define RT_LDS_SPHERES 256u
 #define RT_CHUNK_BVH 8u
+// samples per slice: 64, doubled until at most 16 slices cover spp; a function of spp alone, always a power of two
+#define RT_SLICE_SPP 64u
+#define RT_MAX_SLICES 16u
+#define RT_SLICE_BELOW_BLOCKS 12000u /* launches of fewer workgroups than this are sliced */
 #define RT_T_MIN 0.001f      /* raytracer_core/src/shapes/ray.rs:5 */
 #define RT_T_MAX 100000.0f   /* raytracer_core/src/shapes/ray.rs:6 */
 
@@ -98,6 +102,9 @@ struct KernelParams {
     float *accum_out;    // optional caller copy (may be null)
     uint32_t *rgba8;     // optional, owned_rows*width (R | G<<8 | B<<16 | 255<<24)
     unsigned long long *stats;  // RT_STAT_* counters, RT_STAT_SHARDS shards of RT_STAT_N
+    // sample slicing: blockIdx.y = slice of slice_spp samples; partial sums [n_slices][owned_rows*width][3] when n_slices > 1
+    uint32_t slice_spp, n_slices;
+    float *partial;
     // RTHIP_F_ADAPTIVE (lib.rs:276-313)
     uint32_t *pix_state;          // per owned pixel: RT_PIX_* word (null: not adaptive)
     const uint32_t *worklist;     // passes after the first: owned-pixel indices (lrow*width + x) still to trace (null: every pixel)

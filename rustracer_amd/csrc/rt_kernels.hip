@@ -397,6 +397,42 @@ struct Surface {
     float tu, tv, tw;  // sphere: (p-c).z, (p-c).x, (p-c).y/r for the texture coordinates (sphere.rs:67-73)
 };
 
+// The end of generate_pixel for one pixel — lib.rs:289-313: add the prior running sum, store it, tonemap, and (adaptive)
+// the convergence rule. Returns the bits to add to the PIX_TRACED / PIX_FINAL counters.
+__device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f3 acc, uint32_t &traced, uint32_t &fin_out) {
+    if (P.accumulate) {
+        acc.x += P.accum[oi * 3 + 0];
+        acc.y += P.accum[oi * 3 + 1];
+        acc.z += P.accum[oi * 3 + 2];
+    }
+    P.accum[oi * 3 + 0] = acc.x;
+    P.accum[oi * 3 + 1] = acc.y;
+    P.accum[oi * 3 + 2] = acc.z;
+    if (P.accum_out) {
+        P.accum_out[oi * 3 + 0] = acc.x;
+        P.accum_out[oi * 3 + 1] = acc.y;
+        P.accum_out[oi * 3 + 2] = acc.z;
+    }
+    if (P.rgba8 || P.pix_state) {
+        // mean, clamp(0,1), sqrt, *255, `as u8` (truncate, saturate, NaN -> 0): lib.rs:294-299,30-38
+        float cr = __fsqrt_rn(fminf(fmaxf(acc.x * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
+        float cg = __fsqrt_rn(fminf(fmaxf(acc.y * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
+        float cb = __fsqrt_rn(fminf(fmaxf(acc.z * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
+        const uint32_t rgb = uint32_t(cr) | (uint32_t(cg) << 8) | (uint32_t(cb) << 16);
+        if (P.rgba8) P.rgba8[oi] = rgb | 0xff000000u;
+        if (P.pix_state) {
+            // lib.rs:300-313: compare with last_color, count equal passes, Final after more than 3
+            const uint32_t st = P.pix_state[oi];
+            uint32_t count = (st >> RT_PIX_COUNT_SHIFT) & RT_PIX_COUNT_MASK;
+            if (st & RT_PIX_HAS_LAST) count = ((st & RT_PIX_RGB_MASK) == rgb) ? count + 1u : 0u;
+            const bool fin = count > 3u;  // MAX_SIMILAR_SAMPLE_FOR_A_PIXEL, lib.rs:244,309
+            P.pix_state[oi] = rgb | (count << RT_PIX_COUNT_SHIFT) | (fin ? RT_PIX_FINAL : 0u) | RT_PIX_HAS_LAST;
+            traced++;
+            fin_out += fin ? 1u : 0u;
+        }
+    }
+}
+
 // One full pass over the frame: generate_pixel (lib.rs:269-316) with project_ray (ray.rs:42-87) inlined.
 //
 // Work distribution inside a wave (a wave owns an 8x8 pixel tile).
@@ -416,7 +452,7 @@ struct Surface {
 // [MODE_BVH: bvh_levels x 256 x 4 traversal stack | 4 waves x 64 x 16 per-pixel {base direction, RNG key}
 // | 4 waves x 3 x 64*chunk x 4 radiance slots]; rt_launch_render computes the size.
 template <bool STATS, int MODE, bool LIGHTS>
-__global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
+__global__ __launch_bounds__(256, (LIGHTS || STATS) ? 4 : (MODE == MODE_BVH ? 5 : 7)) void render_kernel(const KernelParams P) {
     constexpr bool POOL = MODE == MODE_BVH;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     rt_f4 *s_geom_mem = (rt_f4 *)s_dyn;
@@ -431,6 +467,15 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
         __syncthreads();
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // Sample slicing (strong scaling): blockIdx.y traces samples [slice*slice_spp, ...) of its pixels, so that a workgroup
+    // lives for at most slice_spp samples however large spp is — with one workgroup per tile for all 256 spp, the last
+    // workgroups of a 1/8-frame launch ran for a third of the kernel on a mostly idle GPU (73 % kernel efficiency at 8 GPUs).
+    // Whether a launch is sliced is a scheduling decision (rt_launch_render: only when the grid is too small to fill the
+    // GPU otherwise); the IMAGE does not depend on it, because the unsliced kernel adds the samples in the same groups:
+    // sum = (...((g0 + g1) + g2)...), g_k = the sequential sum of samples [k*slice_spp, (k+1)*slice_spp).
+    const bool sliced = P.n_slices > 1;
+    const uint32_t s_first = sliced ? blockIdx.y * P.slice_spp : 0u;
+    const uint32_t n_spp = sliced ? min(P.slice_spp, P.spp - s_first) : P.spp;
     uint32_t x, lrow;
     bool listed = true;
     if (P.worklist) {
@@ -655,7 +700,7 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
         // Second half: the lane's next ray — the scattered ray of the surface shade() left behind, or
         // (fresh) the primary ray of a new sample. Both need one RNG pair and one normalisation; sharing
         // them halves that cost in a wave where some lanes continue and the others start a new path.
-        uint32_t key_own = rt_counter(__float_as_uint(pp_own.w), P.sample0, 0);  // !POOL: slot 0 of this pixel's next sample
+        uint32_t key_own = rt_counter(__float_as_uint(pp_own.w), P.sample0 + s_first, 0);  // !POOL: slot 0 of this pixel's next sample
         auto next_ray = [&](bool fresh, uint32_t pixel, uint32_t sample) {
             rt_f4 pp = pp_own;
             uint32_t k = key + RT_RNG_GOLDEN;  // RNG slot 1 + bounce
@@ -722,22 +767,31 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
         if constexpr (!POOL) {
             // ---- lane = pixel: path regeneration over the pixel's samples ----
             if (active) {
-                uint32_t s_left = P.spp;
+                uint32_t s_done = 0;
+                const uint32_t g_mask = P.slice_spp - 1u;  // slice_spp is a power of two
+                f3 grp = mk3(0.0f, 0.0f, 0.0f);            // sum of the current group of slice_spp samples
                 next_ray(true, lane, 0);
                 for (;;) {
                     f3 L;
                     const bool fresh = shade(L) != 0;
                     if (fresh) {
-                        acc = acc + L;  // lib.rs:287
-                        cnt[RT_STAT_PATHS]++;
-                        if (--s_left == 0) break;
+                        grp = grp + L;  // lib.rs:287
+                        s_done++;
+                        if (s_done == n_spp) break;
+                        if ((s_done & g_mask) == 0u) {
+                            acc = acc + grp;
+                            grp = mk3(0.0f, 0.0f, 0.0f);
+                        }
                     }
                     next_ray(fresh, lane, 0);
                 }
+                acc = acc + grp;
+                cnt[RT_STAT_PATHS] += s_done;
             }
         } else {
-            for (uint32_t s_base = 0; s_base < P.spp; s_base += P.chunk) {
-                const uint32_t total = min(P.chunk, P.spp - s_base) << 6;  // work items of this chunk
+            f3 grp = mk3(0.0f, 0.0f, 0.0f);  // sum of the current group of slice_spp samples (chunk divides slice_spp)
+            for (uint32_t s_base = 0; s_base < n_spp; s_base += P.chunk) {
+                const uint32_t total = min(P.chunk, n_spp - s_base) << 6;  // work items of this chunk
                 uint32_t next = 0;                                          // first item not yet handed out (wave-uniform)
                 bool have = false;                                          // this lane is tracing a path
                 for (;;) {
@@ -748,7 +802,7 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                         if (idx < total && ((amask >> (idx & 63u)) & 1ull)) {
                             item = idx;
                             have = true;
-                            next_ray(true, idx & 63u, P.sample0 + s_base + (idx >> 6));
+                            next_ray(true, idx & 63u, P.sample0 + s_first + s_base + (idx >> 6));
                         }
                     }
                     next = min(next + uint32_t(__popcll(need)), total);
@@ -772,9 +826,13 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
                 __builtin_amdgcn_wave_barrier();
                 if (active) {
                     for (uint32_t k = lane; k < total; k += 64u) {
-                        acc.x += s_L[k];
-                        acc.y += s_L[plane + k];
-                        acc.z += s_L[2u * plane + k];
+                        grp.x += s_L[k];
+                        grp.y += s_L[plane + k];
+                        grp.z += s_L[2u * plane + k];
+                    }
+                    if ((s_base + P.chunk) % P.slice_spp == 0u || s_base + P.chunk >= n_spp) {
+                        acc = acc + grp;
+                        grp = mk3(0.0f, 0.0f, 0.0f);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -782,38 +840,13 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
             }
         }
         if (active) {
-            // lib.rs:289-299: add the prior running sum, store it, tonemap
             const size_t oi = size_t(lrow) * P.width + x;
-            if (P.accumulate) {
-                acc.x += P.accum[oi * 3 + 0];
-                acc.y += P.accum[oi * 3 + 1];
-                acc.z += P.accum[oi * 3 + 2];
-            }
-            P.accum[oi * 3 + 0] = acc.x;
-            P.accum[oi * 3 + 1] = acc.y;
-            P.accum[oi * 3 + 2] = acc.z;
-            if (P.accum_out) {
-                P.accum_out[oi * 3 + 0] = acc.x;
-                P.accum_out[oi * 3 + 1] = acc.y;
-                P.accum_out[oi * 3 + 2] = acc.z;
-            }
-            if (P.rgba8 || P.pix_state) {
-                // mean, clamp(0,1), sqrt, *255, `as u8` (truncate, saturate, NaN -> 0): lib.rs:294-299,30-38
-                float cr = __fsqrt_rn(fminf(fmaxf(acc.x * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
-                float cg = __fsqrt_rn(fminf(fmaxf(acc.y * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
-                float cb = __fsqrt_rn(fminf(fmaxf(acc.z * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
-                const uint32_t rgb = uint32_t(cr) | (uint32_t(cg) << 8) | (uint32_t(cb) << 16);
-                if (P.rgba8) P.rgba8[oi] = rgb | 0xff000000u;
-                if (P.pix_state) {
-                    // lib.rs:300-313: compare with last_color, count equal passes, Final after more than 3
-                    const uint32_t st = P.pix_state[oi];
-                    uint32_t count = (st >> RT_PIX_COUNT_SHIFT) & RT_PIX_COUNT_MASK;
-                    if (st & RT_PIX_HAS_LAST) count = ((st & RT_PIX_RGB_MASK) == rgb) ? count + 1u : 0u;
-                    const bool fin = count > 3u;  // MAX_SIMILAR_SAMPLE_FOR_A_PIXEL, lib.rs:244,309
-                    P.pix_state[oi] = rgb | (count << RT_PIX_COUNT_SHIFT) | (fin ? RT_PIX_FINAL : 0u) | RT_PIX_HAS_LAST;
-                    cnt[RT_STAT_PIX_TRACED]++;
-                    cnt[RT_STAT_PIX_FINAL] += fin ? 1u : 0u;
-                }
+            if (sliced) {
+                // sample slicing: this workgroup traced one slice of the pixel's samples; resolve_kernel adds the slices in order
+                float *part = P.partial + (size_t(blockIdx.y) * P.owned_rows * P.width + oi) * 3;
+                part[0] = acc.x, part[1] = acc.y, part[2] = acc.z;
+            } else {
+                finish_pixel(P, oi, acc, cnt[RT_STAT_PIX_TRACED], cnt[RT_STAT_PIX_FINAL]);
             }
         }
     }
@@ -826,6 +859,36 @@ __global__ __launch_bounds__(256) void render_kernel(const KernelParams P) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if (lane == 0 && v) atomicAdd(&P.stats[(blockIdx.x & (RT_STAT_SHARDS - 1)) * RT_STAT_N + i], (unsigned long long)v);
+    }
+}
+
+// Sample slicing, second half: pixel sums = slice 0 + slice 1 + ... in slice order (a fixed order: the image does not depend
+// on how many GPUs share the frame), then the end of generate_pixel. Thread i handles owned pixel i (or the i-th listed pixel).
+__global__ __launch_bounds__(256) void resolve_kernel(const KernelParams P) {
+    const uint32_t gi = blockIdx.x * 256u + threadIdx.x;
+    const size_t npx = size_t(P.owned_rows) * P.width;
+    bool in = gi < npx;
+    size_t oi = gi;
+    if (P.worklist) {
+        in = gi < *P.worklist_count;
+        oi = in ? P.worklist[gi] : 0u;
+    }
+    uint32_t traced = 0, fin = 0;
+    if (in) {
+        f3 acc = mk3(0.0f, 0.0f, 0.0f);
+        for (uint32_t k = 0; k < P.n_slices; k++) {
+            const float *part = P.partial + (size_t(k) * npx + oi) * 3;
+            acc.x += part[0], acc.y += part[1], acc.z += part[2];
+        }
+        finish_pixel(P, oi, acc, traced, fin);
+    }
+    if (P.pix_state) {
+        const unsigned long long tm = __ballot(traced != 0), fm = __ballot(fin != 0);
+        if ((threadIdx.x & 63u) == 0) {
+            unsigned long long *sh = &P.stats[(blockIdx.x & (RT_STAT_SHARDS - 1)) * RT_STAT_N];
+            if (tm) atomicAdd(&sh[RT_STAT_PIX_TRACED], (unsigned long long)__popcll(tm));
+            if (fm) atomicAdd(&sh[RT_STAT_PIX_FINAL], (unsigned long long)__popcll(fm));
+        }
     }
 }
 
@@ -891,9 +954,9 @@ __global__ void pick_kernel(const KernelParams P, float u, float v, long long *o
 template <bool STATS, int MODE>
 static void launch_variant(const KernelParams &P, bool lights, uint32_t blocks, uint32_t lds, hipStream_t stream) {
     if (lights)
-        hipLaunchKernelGGL((render_kernel<STATS, MODE, true>), dim3(blocks), dim3(256), lds, stream, P);
+        hipLaunchKernelGGL((render_kernel<STATS, MODE, true>), dim3(blocks, P.n_slices), dim3(256), lds, stream, P);
     else
-        hipLaunchKernelGGL((render_kernel<STATS, MODE, false>), dim3(blocks), dim3(256), lds, stream, P);
+        hipLaunchKernelGGL((render_kernel<STATS, MODE, false>), dim3(blocks, P.n_slices), dim3(256), lds, stream, P);
 }
 
 template <bool STATS>
@@ -909,7 +972,11 @@ static uint32_t default_chunk() {
         const char *e = getenv("RTHIP_CHUNK");  // tuning knob; results do not depend on it
         return e ? atoi(e) : 0;
     }();
-    if (env > 0) return uint32_t(env > 16 ? 16 : env);
+    if (env > 0) {
+        uint32_t c = 1;
+        while (c * 2 <= uint32_t(env) && c < 16) c *= 2;  // a power of two, so that it divides the sample-group size
+        return c;
+    }
     return RT_CHUNK_BVH;
 }
 
@@ -933,8 +1000,19 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
         lds = (mode == MODE_LDS) ? (RT_LDS_SPHERES + 3u * P.n_spheres) * 16u : 16u;
     }
     if (lds > 65536u) return hipErrorInvalidValue;
+    if (P.n_slices == 0 || P.slice_spp == 0 || (P.n_slices > 1 && (uint64_t(P.n_slices) * P.slice_spp < P.spp || !P.partial))) return hipErrorInvalidValue;
+    if (mode == MODE_BVH) {
+        while (P.chunk > 1 && P.slice_spp % P.chunk) P.chunk >>= 1;  // a chunk never straddles two sample groups
+    }
+    // slice only when the launch would otherwise be too coarse to fill the GPU to its end (measured on the C2 frame:
+    // whole frame 32 400 workgroups: slicing costs 3 %; 1/8 of it: unsliced 73 %, sliced 91 % of ideal); same image either way
+    if (blocks >= RT_SLICE_BELOW_BLOCKS) P.n_slices = 1;
     if (count_stats) launch_mode<true>(P, mode, lights, blocks, lds, stream);
     else launch_mode<false>(P, mode, lights, blocks, lds, stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || P.n_slices == 1) return e;
+    const uint32_t rblocks = uint32_t((uint64_t(P.owned_rows) * P.width + 255u) / 256u);
+    hipLaunchKernelGGL(resolve_kernel, dim3(rblocks), dim3(256), 0, stream, P);
     return hipGetLastError();
 }
 

@@ -37,7 +37,7 @@ struct rthip_ctx {
     int device = 0;
     std::string err;
     DevBuf sph_geom, sph_shade, pln_geom, tri_geom, materials, texels, tex_info, lights, bvh_nodes, bvh_recs;
-    DevBuf stats, accum, staging_rgba, staging_accum, pick_out, pix_state, worklist;
+    DevBuf stats, accum, staging_rgba, staging_accum, pick_out, pix_state, worklist, partial;
     KernelParams base;
     bool have_scene = false, have_camera = false;
     rthip_camera camera;
@@ -249,7 +249,7 @@ void rthip_destroy(rthip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->sph_geom, &ctx->sph_shade, &ctx->pln_geom, &ctx->tri_geom, &ctx->materials, &ctx->texels, &ctx->tex_info, &ctx->lights,
-                      &ctx->bvh_nodes, &ctx->bvh_recs, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out, &ctx->pix_state, &ctx->worklist})
+                      &ctx->bvh_nodes, &ctx->bvh_recs, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out, &ctx->pix_state, &ctx->worklist, &ctx->partial})
         b->release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -521,6 +521,18 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rg
         k.rgba8 = (uint32_t *)d_rgba8;
         k.stats = (unsigned long long *)ctx->stats.p;
         if (p->flags & RTHIP_F_NO_BVH) k.n_bvh_nodes = 0;
+        // sample slicing: a function of spp alone, so that the image is the same for every band layout / GPU count
+        k.slice_spp = RT_SLICE_SPP;
+        while (uint64_t(k.slice_spp) * RT_MAX_SLICES < p->spp) k.slice_spp *= 2;  // a power of two (the kernels mask with slice_spp - 1)
+        k.n_slices = (p->spp + k.slice_spp - 1) / k.slice_spp;
+        // ... but whether the launch IS sliced only depends on its size (rt_launch_render applies the same rule)
+        const uint64_t groups = (p->flags & RTHIP_F_ADAPTIVE) && accumulate ? (uint64_t(rows) * p->width + 255u) / 256u
+                                                                             : uint64_t((p->width + 15u) / 16u) * ((rows + 15u) / 16u);
+        if (groups >= RT_SLICE_BELOW_BLOCKS) k.n_slices = 1;
+        if (k.n_slices > 1) {
+            if ((st = ensure(ctx, ctx->partial, size_t(k.n_slices) * rows * p->width * 3 * sizeof(float)))) return st;
+            k.partial = (float *)ctx->partial.p;
+        }
 
         HIPCHK(ctx, hipMemsetAsync(ctx->stats.p, 0, ctx->stats.bytes, stream));
         if (stats) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));

@@ -314,6 +314,20 @@ def test_full_size_4k_properties(standalone_flat):
         part = rt.render(standalone_flat, spp, max_depth=depth, band_rows=8, band_first=rank, band_stride=8, want_accum=False)
         full[owned_row_indices(h, 8, rank, 8)] = part.rgba8
     assert zlib.crc32(full.tobytes()) == zlib.crc32(whole.rgba8.tobytes())
+    # sample slicing is a scheduling decision only: the whole frame (32 400 workgroups, unsliced) and 1/8-frame launches
+    # (sliced into groups of 64 samples + resolve) give the same bytes and the same running sums, also when accumulating
+    big = [rt.render(standalone_flat, 130, max_depth=depth, accumulate=k > 0) for k in range(2)][-1]
+    parts = Raytracer.new(w, h, seed=71)
+    acc8, img8 = np.empty_like(big.accum), np.empty_like(big.rgba8)
+    for rank in range(8):
+        rows = owned_row_indices(h, 8, rank, 8)
+        for k in range(2):
+            part = parts.render(standalone_flat, 130, max_depth=depth, accumulate=k > 0, band_rows=8, band_first=rank, band_stride=8)
+        parts.invalidate_pixels()
+        acc8[rows], img8[rows] = part.accum, part.rgba8
+    assert np.array_equal(acc8, big.accum) and np.array_equal(img8, big.rgba8)
+    assert big.stats["nb_samples"] == 260
+    parts.close()
     # top rows are sky (blue channel saturated), bottom rows are the teal ground (red == 0)
     assert (whole.rgba8[-1, :, 2] == 255).all() and (whole.rgba8[0, :, 0] == 0).all()
     # tonemap identity on the device's own sums: u8 == trunc(255*sqrt(clamp(sum/n)))
