@@ -554,12 +554,26 @@ __global__ __launch_bounds__(256, (LIGHTS || STATS) ? 4 : (MODE == MODE_BVH ? 5 
         bool dead = false;  // the last scatter absorbed the path (metal.rs:62-64): it ends, with L = T, at the next shade()
         // First half of a segment: closest hit and shading. Returns 1 = the path ended with radiance L,
         // 0 = it goes on (next_ray(false) scatters it), 2 (MODE_BVH) = the ray is parked inside the tree.
-        auto shade = [&](f3 &L) -> int {
+        f3 grp = mk3(0.0f, 0.0f, 0.0f);  // sum of the current group of slice_spp samples
+        // a finished path hands its radiance over where it ends (not through a merged return value: that costs copies)
+        auto emit = [&](f3 L) {
+            if (LIGHTS) L = L + Ld;
+            if constexpr (POOL) {
+                s_L[item] = L.x;  // lib.rs:287, summed in sample order at the end of the chunk
+                s_L[plane + item] = L.y;
+                s_L[2u * plane + item] = L.z;
+            } else {
+                // no fused multiply-add of the caller's T*colour into the sum: the work-pool variant stores the rounded
+                // product first, and "BVH == linear scan bit for bit" (tests) compares the two variants
+                asm volatile("" : "+v"(L.x), "+v"(L.y), "+v"(L.z));
+                grp = grp + L;  // lib.rs:287
+            }
+        };
+        auto shade = [&]() -> int {
             bool done;
             if (dead) {  // None -> new_color alone, ray.rs:80
                 dead = false;
-                L = T;
-                if (LIGHTS) L = L + Ld;
+                emit(T);
                 return 1;
             }
             if (MODE == MODE_BVH) {
@@ -587,7 +601,7 @@ __global__ __launch_bounds__(256, (LIGHTS || STATS) ? 4 : (MODE == MODE_BVH ? 5 
             if (h.shape == RT_NONE) {  // ray.rs:85, background_color ray.rs:89-93 (the direction is already unit)
                 const float t = fmaf(0.5f, r.d.y, 0.5f);
                 const float w = 1.0f - t;
-                L = T * mk3(fmaf(0.5f, t, w), fmaf(0.7f, t, w), w + t);
+                emit(T * mk3(fmaf(0.5f, t, w), fmaf(0.7f, t, w), w + t));
                 done = true;
                 if (STATS) cnt[RT_STAT_SKY]++;
             } else {
@@ -655,7 +669,7 @@ __global__ __launch_bounds__(256, (LIGHTS || STATS) ? 4 : (MODE == MODE_BVH ? 5 
                     const uint32_t tyl = texture_wrap(V, sf.param, ti.height);
                     const uint32_t texel = P.texels[ti.first_texel + (((tyl >> 3) * ti.tiles_per_row + (txl >> 3)) << 6) + ((tyl & 7u) << 3) + (txl & 7u)];
                     const f3 c = mk3(float(texel & 255u), float((texel >> 8) & 255u), float((texel >> 16) & 255u)) * (1.0f / 255.0f);
-                    L = T * c;
+                    emit(T * c);
                     done = true;
                 } else {
                     cosi = dot(r.d, sf.n);
@@ -694,7 +708,6 @@ __global__ __launch_bounds__(256, (LIGHTS || STATS) ? 4 : (MODE == MODE_BVH ? 5 
                     done = false;
                 }
             }
-            if (done && LIGHTS) L = L + Ld;
             return done ? 1 : 0;
         };
         // Second half: the lane's next ray — the scattered ray of the surface shade() left behind, or
@@ -769,13 +782,10 @@ __global__ __launch_bounds__(256, (LIGHTS || STATS) ? 4 : (MODE == MODE_BVH ? 5 
             if (active) {
                 uint32_t s_done = 0;
                 const uint32_t g_mask = P.slice_spp - 1u;  // slice_spp is a power of two
-                f3 grp = mk3(0.0f, 0.0f, 0.0f);            // sum of the current group of slice_spp samples
                 next_ray(true, lane, 0);
                 for (;;) {
-                    f3 L;
-                    const bool fresh = shade(L) != 0;
+                    const bool fresh = shade() != 0;
                     if (fresh) {
-                        grp = grp + L;  // lib.rs:287
                         s_done++;
                         if (s_done == n_spp) break;
                         if ((s_done & g_mask) == 0u) {
@@ -789,7 +799,6 @@ __global__ __launch_bounds__(256, (LIGHTS || STATS) ? 4 : (MODE == MODE_BVH ? 5 
                 cnt[RT_STAT_PATHS] += s_done;
             }
         } else {
-            f3 grp = mk3(0.0f, 0.0f, 0.0f);  // sum of the current group of slice_spp samples (chunk divides slice_spp)
             for (uint32_t s_base = 0; s_base < n_spp; s_base += P.chunk) {
                 const uint32_t total = min(P.chunk, n_spp - s_base) << 6;  // work items of this chunk
                 uint32_t next = 0;                                          // first item not yet handed out (wave-uniform)
@@ -808,12 +817,8 @@ __global__ __launch_bounds__(256, (LIGHTS || STATS) ? 4 : (MODE == MODE_BVH ? 5 
                     next = min(next + uint32_t(__popcll(need)), total);
                     if (__ballot(have) == 0ull) break;
                     if (have) {
-                        f3 L;
-                        const int st = shade(L);
+                        const int st = shade();
                         if (st == 1) {
-                            s_L[item] = L.x;  // lib.rs:287, summed in sample order below
-                            s_L[plane + item] = L.y;
-                            s_L[2u * plane + item] = L.z;
                             cnt[RT_STAT_PATHS]++;
                             have = false;
                         } else if (st == 0) {
