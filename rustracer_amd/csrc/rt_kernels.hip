@@ -784,6 +784,12 @@ __global__ __launch_bounds__(256, (LIGHTS || STATS) ? 4 : (MODE == MODE_BVH ? 5 
                 const uint32_t g_mask = P.slice_spp - 1u;  // slice_spp is a power of two
                 next_ray(true, lane, 0);
                 for (;;) {
+#ifdef RT_BVH_DEBUG_UTIL
+                    if (STATS) {  // wave iterations x 64 (vs `rays` = lane iterations): the lanes a wave idles at its end
+                        const unsigned long long ex = __ballot(true);
+                        if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex), 0u)) == 0) cnt[RT_STAT_SHADOW] += 64;
+                    }
+#endif
                     const bool fresh = shade() != 0;
                     if (fresh) {
                         s_done++;
