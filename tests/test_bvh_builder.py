@@ -1,0 +1,34 @@
+"""Host logic without a GPU: the BVH builder (rustracer_amd/csrc/rt_bvh.cpp) under AddressSanitizer + UBSan against the
+invariants the device traversal relies on (tests/native/bvh_check.cpp): reachability, leaf partition, box containment,
+stack depth. Covers empty, tiny, coincident, collinear, clustered and large inputs."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "native", "bvh_check.cpp")
+BVH = os.path.join(ROOT, "rustracer_amd", "csrc", "rt_bvh.cpp")
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("bvh") / "bvh_check")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe, SRC, BVH],
+                   check=True, cwd=ROOT)
+    return exe
+
+
+@pytest.mark.parametrize("ns,nt,seed,layout", [
+    (0, 0, 1, 0), (1, 0, 1, 0), (0, 1, 2, 0), (3, 2, 3, 0), (4, 0, 4, 0), (5, 0, 5, 0),
+    (65, 0, 6, 0), (401, 320, 7, 0), (0, 20480, 8, 0), (10001, 81920, 9, 0),
+    (300, 300, 10, 1),     # every centroid coincides: median splits by index
+    (1000, 0, 11, 2),      # collinear
+    (5000, 5000, 12, 3),   # tight clusters far apart
+    (200000, 0, 13, 0),
+    (190, 0, 14, 4), (1900, 0, 15, 4),   # unbalanced SAH splits: depth capped at RT_BVH_MAX_DEPTH by median splits
+])
+def test_bvh_invariants(checker, ns, nt, seed, layout):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:verify_asan_link_order=0")
+    r = subprocess.run([checker, str(ns), str(nt), str(seed), str(layout)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
