@@ -295,10 +295,19 @@ __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &
         // tracked negated: nbest = -h.t, starting just above -tmax, so "not (n < nbest)" <=> t <= best < tmax
         float nbest = -h.t;
         const float ntmin = -r.tmin;
-#pragma unroll 4
         for (uint32_t i = 0; i < P.n_spheres; i++) {  // wave-uniform LDS address: broadcast read, VGPR operands
-            float n0, n1;
-            sphere_roots(s_geom[i], r, i == self, n0, n1);
+            const rt_f4 g = s_geom[i];
+            const f3 oc = mk3(r.o.x - g.x, r.o.y - g.y, r.o.z - g.z);
+            const float half_b = dot(oc, r.d);
+            float c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -g.w)));
+            c = (i == self) ? 0.0f : c;  // sphere_roots: exact c for the sphere the ray starts on
+            const float disc = fmaf(half_b, half_b, -c);
+            // most spheres are missed by every ray of the wave (coherent primary rays, small spheres): then the square root,
+            // both roots and the window/closest selects (half of the test, ~40 issue cycles) are skipped. A lane's own result
+            // never depends on its neighbours: with disc < 0 (or NaN) the skipped code selects nothing either.
+            if (__ballot(disc >= 0.0f) == 0ull) continue;
+            const float root = fast_sqrt(disc);
+            const float n0 = half_b + root, n1 = half_b - root;
             const float n = (n0 < ntmin) ? n0 : n1;
             const bool take = (n1 < ntmin) & !(n < nbest);
             nbest = take ? n : nbest;
