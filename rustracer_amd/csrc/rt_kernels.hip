@@ -758,8 +758,9 @@ __global__ __launch_bounds__(256, (LIGHTS || STATS) ? 4 : (MODE == MODE_BVH ? 5 
                 const f3 base = lambert ? sf.n : refl;
                 const float wf = lambert ? 1.0f : sf.param;
                 nd = fma3(w, wf, base);
-                // metal.rs:62-64: absorbed if the new direction points into the surface (never true for n + w)
-                dead = dot(nd, sf.n) < 0.0f;
+                // metal.rs:62-64: absorbed if the new direction points into the surface. Lambertian::bounce always returns a ray
+                // (lambertian_diffuse.rs:68-73), also when rounding puts n + w a hair below the surface
+                dead = !lambert && dot(nd, sf.n) < 0.0f;
                 if (sf.kind == RTHIP_MAT_DIELECTRIC) {  // dielectric.rs:68-98
                     // dot_product = direction . normal with the UN-normalised direction; len() is the element count 3: dielectric.rs:74-83
                     const float len = r.tmin * (1.0f / RT_T_MIN);  // |direction|
