@@ -18,7 +18,9 @@
 #define RT_LDS_SPHERES 256u
 #define RT_CHUNK_BVH 8u
 // samples per slice: 64, doubled until at most 16 slices cover spp; a function of spp alone, always a power of two
+#ifndef RT_SLICE_SPP
 #define RT_SLICE_SPP 64u
+#endif
 #define RT_MAX_SLICES 16u
 #define RT_SLICE_BELOW_BLOCKS 12000u /* launches of fewer workgroups than this are sliced */
 #define RT_T_MIN 0.001f      /* raytracer_core/src/shapes/ray.rs:5 */
