@@ -68,6 +68,8 @@ extern "C" {
                                hip_stream: *mut c_void, stats: *mut rthip_stats) -> c_int;
     pub fn rthip_reset_accum(ctx: *mut rthip_ctx) -> c_int;
     pub fn rthip_pixel_status(ctx: *mut rthip_ctx, status_out: *mut u8, same_color_count_out: *mut u8) -> c_int;
+    pub fn rthip_host_alloc(bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
+    pub fn rthip_host_free(ptr: *mut c_void) -> c_int;
     pub fn rthip_pick(ctx: *mut rthip_ctx, width: u32, height: u32, x: f64, y: f64, out_shape: *mut i64) -> c_int;
     pub fn rthip_algorithmic_flops(stats: *const rthip_stats) -> f64;
     pub fn rthip_last_error(ctx: *const rthip_ctx) -> *const c_char;

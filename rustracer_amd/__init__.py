@@ -6,6 +6,6 @@ scene/render API), `presets` (the benchmark scenes), `bands` (multi-GPU row-band
 """
 from . import abi  # noqa: F401
 from .raytracer import (GenerationStatus, PixelColor, PixelPosition, PixelRenderer, Raytracer, RenderResult,  # noqa: F401
-                        make_params, owned_rows)
+                        host_array, make_params, owned_rows)
 from .scene import (Camera, Dielectric, FlatScene, Lambertian, Mesh, Metal, Plane, PointLight, Sphere, SphereCloud,  # noqa: F401
                     Texture, Triangle, Vector3, flatten)

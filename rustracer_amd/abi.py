@@ -96,6 +96,8 @@ SYMBOLS = {
     "rthip_render_device": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]),
     "rthip_reset_accum": (C.c_int, [C.c_void_p]),
     "rthip_pixel_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rthip_host_alloc": (C.c_int, [C.c_size_t, _P(C.c_void_p)]),
+    "rthip_host_free": (C.c_int, [C.c_void_p]),
     "rthip_pick": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _P(C.c_int64)]),
     "rthip_algorithmic_flops": (C.c_double, [_P(Stats)]),
     "rthip_last_error": (C.c_char_p, [C.c_void_p]),

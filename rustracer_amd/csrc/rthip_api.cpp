@@ -619,6 +619,21 @@ int rthip_render(rthip_ctx *ctx, const rthip_render_params *p, uint8_t *rgba8_ou
     }
 }
 
+int rthip_host_alloc(size_t bytes, void **out_ptr) {
+    if (!out_ptr || bytes == 0) return fail(nullptr, RTHIP_E_BADARG, "rthip_host_alloc: bad arguments");
+    *out_ptr = nullptr;
+    hipError_t e = hipHostMalloc(out_ptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(nullptr, e == hipErrorOutOfMemory ? RTHIP_E_OOM : RTHIP_E_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    return RTHIP_OK;
+}
+
+int rthip_host_free(void *ptr) {
+    if (!ptr) return RTHIP_OK;
+    hipError_t e = hipHostFree(ptr);
+    if (e != hipSuccess) return fail(nullptr, RTHIP_E_HIP, std::string("hipHostFree: ") + hipGetErrorString(e));
+    return RTHIP_OK;
+}
+
 int rthip_pick(rthip_ctx *ctx, uint32_t width, uint32_t height, double x, double y, int64_t *out_shape) {
     if (!ctx) return RTHIP_E_BADARG;
     if (!out_shape || width < 2 || height < 2) return fail(ctx, RTHIP_E_BADARG, "bad pick arguments");

@@ -95,6 +95,29 @@ def owned_rows(params: abi.RenderParams) -> int:
     return rows.value
 
 
+class _PinnedBlock:
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        _check(abi.lib().rthip_host_alloc(nbytes, C.byref(self.ptr)))
+
+    def __del__(self):
+        try:
+            abi.lib().rthip_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def host_array(shape, dtype=np.uint8):
+    """numpy array in page-locked host memory (rthip_host_alloc), for the image outputs of Raytracer.render"""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape))
+    block = _PinnedBlock(max(1, n * dtype.itemsize))
+    buf = (C.c_uint8 * (n * dtype.itemsize)).from_address(block.ptr.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+    buf._rthip_block = block
+    return arr
+
+
 class Raytracer:
     """Raytracer<R> with the GPU behind it. `seed` replaces the `random: R` argument (the
     reference's generators are entropy-seeded)."""
@@ -144,7 +167,7 @@ class Raytracer:
 
     # ---- the batch form of generate_pixel ----
     def render(self, scene, samples, renderer: Optional[PixelRenderer] = None, max_depth=50, accumulate=False, flags=0,
-               want_accum=True, band_rows=0, band_first=0, band_stride=1, lights=(), adaptive=False) -> RenderResult:
+               want_accum=True, band_rows=0, band_first=0, band_stride=1, lights=(), adaptive=False, rgba_out=None) -> RenderResult:
         """adaptive: the convergence rule of lib.rs:276-313 — Final pixels are skipped by later (accumulate=True) passes."""
         self._sync_scene_camera(scene, lights)
         fl = flags | (abi.F_ACCUMULATE if accumulate else 0) | (abi.F_ADAPTIVE if adaptive else 0)
@@ -152,7 +175,9 @@ class Raytracer:
         rows = owned_rows(p)
         self._last_rows = rows
         w = int(self.width)
-        rgba = np.empty((rows, w, 4), np.uint8)
+        if rgba_out is not None:  # e.g. a page-locked array from host_array(): a much faster device->host copy
+            assert rgba_out.shape == (rows, w, 4) and rgba_out.dtype == np.uint8 and rgba_out.flags.c_contiguous
+        rgba = rgba_out if rgba_out is not None else np.empty((rows, w, 4), np.uint8)
         acc = np.empty((rows, w, 3), np.float32) if want_accum else None
         st = abi.Stats()
         _check(self._lib.rthip_render(self._ctx, C.byref(p), rgba.ctypes.data, acc.ctypes.data if acc is not None else None, C.byref(st)), self._ctx)

@@ -382,3 +382,20 @@ def test_bvh_point_lights_and_planes(oracle_mod, default_camera):
     print(f"\nbvh+lights+plane: {describe(hist, ok)}; shadow rays device {a.stats['shadow_rays']} oracle {st['shadow_rays']}")
     assert abs(a.stats["shadow_rays"] - st["shadow_rays"]) <= 5e-3 * st["shadow_rays"]
     rt.close()
+
+
+def test_page_locked_outputs(standalone_flat):
+    """rthip_host_alloc: same bytes in a page-locked destination, and a faster device->host copy at 4K"""
+    from rustracer_amd import host_array
+    w, h = 3840, 2160
+    rt = Raytracer.new(w, h, seed=2)
+    pageable = rt.render(standalone_flat, 1, max_depth=5, want_accum=False)
+    pinned = host_array((h, w, 4), np.uint8)
+    pinned[:] = 0
+    res = [rt.render(standalone_flat, 1, max_depth=5, want_accum=False, rgba_out=pinned) for _ in range(3)][-1]
+    assert res.rgba8 is pinned and np.array_equal(pinned, pageable.rgba8)
+    print(f"\n4K RGBA8 device->host: pageable {pageable.stats['d2h_ms']:.2f} ms, page-locked {res.stats['d2h_ms']:.2f} ms")
+    assert res.stats["d2h_ms"] < pageable.stats["d2h_ms"]
+    rt.close()
+    lib = abi.lib()
+    assert lib.rthip_host_alloc(0, C.byref(C.c_void_p())) == abi.E_BADARG and lib.rthip_host_free(None) == 0
