@@ -916,42 +916,67 @@ __global__ __launch_bounds__(256) void resolve_kernel(const KernelParams P) {
 // RTHIP_F_ADAPTIVE, before every pass but the first: the work-list of the pixels that are not Final
 // (generate_pixel returns at once for a Final pixel, lib.rs:277-279). Thread i looks at the i-th
 // pixel in 8x8-tile order, so that 64 consecutive list entries stay a compact patch of the image
-// (coherent primary rays); a wave appends its survivors with one atomic. The order of the list
+// (coherent primary rays); a workgroup of 4096 pixels appends its survivors with one atomic. The order of the list
 // varies from run to run, the image does not: a pixel's samples depend on its index alone.
 // Final pixels get their stored colour written to the image outputs, which therefore need not
 // be the buffers of the previous pass.
-__global__ __launch_bounds__(256) void compact_kernel(const KernelParams P, uint32_t *list, uint32_t *count) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+#define RT_COMPACT_THREADS 1024
+#define RT_COMPACT_ROUNDS 4
+__global__ __launch_bounds__(RT_COMPACT_THREADS) void compact_kernel(const KernelParams P, uint32_t *list, uint32_t *count) {
+    // One atomic per WORKGROUP of 4096 pixels (all waves of a frame bumping one counter serialise in L2: one atomic per wave
+    // made this kernel 0.5-1.5 ms at 4K, ten times the render pass it prepares).
+    __shared__ uint32_t s_wave_total[RT_COMPACT_THREADS / 64];
+    __shared__ uint32_t s_block_base;
     const uint32_t tiles_x = (P.width + 7u) >> 3;
-    const uint32_t tile = i >> 6, in_tile = i & 63u;
-    const uint32_t x = (tile % tiles_x) * 8u + (in_tile & 7u), lrow = (tile / tiles_x) * 8u + (in_tile >> 3);
-    const bool inside = x < P.width && lrow < P.owned_rows;
-    const uint32_t oi = lrow * P.width + x;
-    const uint32_t st = inside ? P.pix_state[oi] : RT_PIX_FINAL;
-    const bool live = inside && !(st & RT_PIX_FINAL);
-    const unsigned long long mask = __ballot(live);
-    uint32_t base = 0;
-    if ((threadIdx.x & 63u) == 0 && mask) base = atomicAdd(count, uint32_t(__popcll(mask)));
-    base = __shfl(base, 0, 64);
-    if (live) list[base + __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u))] = oi;
-    if (inside && !live) {
-        if (P.rgba8) P.rgba8[oi] = (st & RT_PIX_RGB_MASK) | 0xff000000u;
-        if (P.accum_out) {
-            P.accum_out[size_t(oi) * 3 + 0] = P.accum[size_t(oi) * 3 + 0];
-            P.accum_out[size_t(oi) * 3 + 1] = P.accum[size_t(oi) * 3 + 1];
-            P.accum_out[size_t(oi) * 3 + 2] = P.accum[size_t(oi) * 3 + 2];
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t oi[RT_COMPACT_ROUNDS], before[RT_COMPACT_ROUNDS];  // my pixel of each round; live pixels of my wave before mine
+    bool live[RT_COMPACT_ROUNDS];
+    uint32_t wave_total = 0, n_final = 0;
+#pragma unroll
+    for (int j = 0; j < RT_COMPACT_ROUNDS; j++) {
+        const uint32_t i = (blockIdx.x * RT_COMPACT_ROUNDS + j) * RT_COMPACT_THREADS + threadIdx.x;
+        const uint32_t tile = i >> 6, in_tile = i & 63u;
+        const uint32_t x = (tile % tiles_x) * 8u + (in_tile & 7u), lrow = (tile / tiles_x) * 8u + (in_tile >> 3);
+        const bool inside = x < P.width && lrow < P.owned_rows;
+        oi[j] = lrow * P.width + x;
+        const uint32_t st = inside ? P.pix_state[oi[j]] : RT_PIX_FINAL;
+        live[j] = inside && !(st & RT_PIX_FINAL);
+        const unsigned long long mask = __ballot(live[j]);
+        before[j] = wave_total + __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
+        wave_total += uint32_t(__popcll(mask));
+        if (inside && !live[j]) {
+            if (P.rgba8) P.rgba8[oi[j]] = (st & RT_PIX_RGB_MASK) | 0xff000000u;
+            if (P.accum_out) {
+                P.accum_out[size_t(oi[j]) * 3 + 0] = P.accum[size_t(oi[j]) * 3 + 0];
+                P.accum_out[size_t(oi[j]) * 3 + 1] = P.accum[size_t(oi[j]) * 3 + 1];
+                P.accum_out[size_t(oi[j]) * 3 + 2] = P.accum[size_t(oi[j]) * 3 + 2];
+            }
         }
+        n_final += uint32_t(__popcll(__ballot(inside && !live[j])));
     }
-    const unsigned long long fmask = __ballot(inside && !live);
-    if ((threadIdx.x & 63u) == 0 && fmask)
-        atomicAdd(&P.stats[(blockIdx.x & (RT_STAT_SHARDS - 1)) * RT_STAT_N + RT_STAT_PIX_FINAL], (unsigned long long)__popcll(fmask));
+    if ((threadIdx.x & 63u) == 0) s_wave_total[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < RT_COMPACT_THREADS / 64; k++) total += s_wave_total[k];
+        s_block_base = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_block_base;
+    for (uint32_t k = 0; k < wave; k++) base += s_wave_total[k];
+#pragma unroll
+    for (int j = 0; j < RT_COMPACT_ROUNDS; j++)
+        if (live[j]) list[base + before[j]] = oi[j];
+    if ((threadIdx.x & 63u) == 0 && n_final)
+        atomicAdd(&P.stats[((blockIdx.x * (RT_COMPACT_THREADS / 64) + wave) & (RT_STAT_SHARDS - 1)) * RT_STAT_N + RT_STAT_PIX_FINAL], (unsigned long long)n_final);
 }
 
 extern "C" hipError_t rt_launch_compact(const KernelParams *P, uint32_t *list, uint32_t *count, hipStream_t stream) {
     const uint32_t tiles = ((P->width + 7u) >> 3) * ((P->owned_rows + 7u) >> 3);
-    const uint32_t blocks = (tiles + 3u) / 4u;  // 4 tiles of 64 pixels per block
+    const uint32_t per_block = RT_COMPACT_THREADS * RT_COMPACT_ROUNDS / 64;  // tiles of 64 pixels per workgroup
+    const uint32_t blocks = (tiles + per_block - 1) / per_block;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(256), 0, stream, *P, list, count);
+    hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(RT_COMPACT_THREADS), 0, stream, *P, list, count);
     return hipGetLastError();
 }
 
