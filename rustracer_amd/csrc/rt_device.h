@@ -124,4 +124,4 @@ enum {
     RT_STAT_PATHS = 0, RT_STAT_RAYS = 1, RT_STAT_SPHERE = 2, RT_STAT_PLANE = 3, RT_STAT_TRI = 4, RT_STAT_NODE = 5,
     RT_STAT_HIT0 = 6 /* +kind, 4 slots */, RT_STAT_SKY = 10, RT_STAT_SHADOW = 11, RT_STAT_PIX_TRACED = 12, RT_STAT_PIX_FINAL = 13, RT_STAT_N = 14
 };
-#define RT_STAT_SHARDS 64
+#define RT_STAT_SHARDS 256 /* 129 600 waves at 4K bump each counter once: few shards serialise in L2 */

@@ -872,14 +872,15 @@ __global__ __launch_bounds__(256, (LIGHTS || STATS) ? 4 : (MODE == MODE_BVH ? 5 
         }
     }
 
-    // per-wave reduction of the counters, one atomic per wave and counter into a shard
+    // per-wave reduction of the counters, one atomic per wave and counter into a shard (skipped when nobody reads them)
+    if (!P.stats) return;
 #pragma unroll
     for (int i = 0; i < RT_STAT_N; i++) {
         if (!STATS && i > RT_STAT_RAYS && i < RT_STAT_PIX_TRACED) continue;
         uint32_t v = cnt[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0 && v) atomicAdd(&P.stats[(blockIdx.x & (RT_STAT_SHARDS - 1)) * RT_STAT_N + i], (unsigned long long)v);
+        if (lane == 0 && v) atomicAdd(&P.stats[((blockIdx.x * 4u + wave) & (RT_STAT_SHARDS - 1)) * RT_STAT_N + i], (unsigned long long)v);
     }
 }
 
@@ -903,7 +904,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const KernelParams P) {
         }
         finish_pixel(P, oi, acc, traced, fin);
     }
-    if (P.pix_state) {
+    if (P.pix_state && P.stats) {
         const unsigned long long tm = __ballot(traced != 0), fm = __ballot(fin != 0);
         if ((threadIdx.x & 63u) == 0) {
             unsigned long long *sh = &P.stats[(blockIdx.x & (RT_STAT_SHARDS - 1)) * RT_STAT_N];
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(RT_COMPACT_THREADS) void compact_kernel(const Kerne
 #pragma unroll
     for (int j = 0; j < RT_COMPACT_ROUNDS; j++)
         if (live[j]) list[base + before[j]] = oi[j];
-    if ((threadIdx.x & 63u) == 0 && n_final)
+    if ((threadIdx.x & 63u) == 0 && n_final && P.stats)
         atomicAdd(&P.stats[((blockIdx.x * (RT_COMPACT_THREADS / 64) + wave) & (RT_STAT_SHARDS - 1)) * RT_STAT_N + RT_STAT_PIX_FINAL], (unsigned long long)n_final);
 }
 

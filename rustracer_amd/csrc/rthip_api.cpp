@@ -519,7 +519,7 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rg
         k.accum = (float *)ctx->accum.p;
         k.accum_out = (float *)d_accum;
         k.rgba8 = (uint32_t *)d_rgba8;
-        k.stats = (unsigned long long *)ctx->stats.p;
+        k.stats = stats ? (unsigned long long *)ctx->stats.p : nullptr;  // no reader, no counting
         if (p->flags & RTHIP_F_NO_BVH) k.n_bvh_nodes = 0;
         // sample slicing: a function of spp alone, so that the image is the same for every band layout / GPU count
         k.slice_spp = RT_SLICE_SPP;
@@ -534,7 +534,7 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rg
             k.partial = (float *)ctx->partial.p;
         }
 
-        HIPCHK(ctx, hipMemsetAsync(ctx->stats.p, 0, ctx->stats.bytes, stream));
+        if (stats) HIPCHK(ctx, hipMemsetAsync(ctx->stats.p, 0, ctx->stats.bytes, stream));
         if (stats) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
         if (adaptive) {
             const size_t npx = size_t(rows) * p->width;

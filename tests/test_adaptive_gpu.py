@@ -35,6 +35,8 @@ def _run_adaptive(flat, w, h, passes, spp, depth, seed, **kw):
     ("standalone_scene", 320, 180, 14, 1, 50),   # the standalone window: progressive, spp = 1 (standalone/src/main.rs:99-102)
     ("standalone_scene", 200, 120, 10, 4, 5),
     ("mesh_small", 192, 108, 9, 2, 8),           # BVH + work pool + work-list
+    ("standalone_scene", 96, 54, 7, 130, 5),     # sample slicing (3 groups: 64 + 64 + 2) + resolve kernel + work-list
+    ("mesh_small", 96, 54, 6, 70, 4),            # the same through the BVH kernel
 ])
 def test_adaptive_rule_matches_reference_state_machine(preset, w, h, passes, spp, depth):
     flat = flatten(presets.mesh_scene(6, 2) if preset == "mesh_small" else getattr(presets, preset)())
