@@ -328,8 +328,21 @@ __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &
     }
     if (MODE != MODE_BVH) {
         for (uint32_t i = 0; i < P.n_tris; i++) {
-            float t, b1, b2;
-            bool ok = hit_tri(P.tri_geom[3 * i], P.tri_geom[3 * i + 1], P.tri_geom[3 * i + 2], r, t, b1, b2);
+            // hit_tri, with a wave-level early-out after the first barycentric (same arithmetic: the skipped half would
+            // reject every lane anyway)
+            const rt_f4 v0 = P.tri_geom[3 * i], e1_ = P.tri_geom[3 * i + 1], e2_ = P.tri_geom[3 * i + 2];
+            const f3 e1 = mk3(e1_.x, e1_.y, e1_.z), e2 = mk3(e2_.x, e2_.y, e2_.z);
+            const f3 pvec = cross(r.d, e2);
+            const float det = dot(e1, pvec);
+            const float inv = fast_rcp(det);
+            const f3 tvec = mk3(r.o.x - v0.x, r.o.y - v0.y, r.o.z - v0.z);
+            const float b1 = dot(tvec, pvec) * inv;
+            const bool first = det != 0.0f && b1 >= 0.0f && b1 <= 1.0f;
+            if (__ballot(first) == 0ull) continue;
+            const f3 qvec = cross(tvec, e1);
+            const float b2 = dot(r.d, qvec) * inv;
+            const float t = dot(e2, qvec) * inv;
+            const bool ok = first && b2 >= 0.0f && (b1 + b2) <= 1.0f && t < r.tmax && t > r.tmin;
             RT_TAKE(ok, t, P.n_spheres + P.n_planes + i, (h.b1 = b1, h.b2 = b2))
         }
         if (STATS) {
