@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <future>
+#include <system_error>
 #include <numeric>
 
 namespace {
@@ -38,14 +40,32 @@ struct Builder {
     std::vector<Box> pbox;       // per primitive
     std::vector<float> centroid; // 3 per primitive
     std::vector<uint32_t> &prims;
-    std::vector<DevBvhNode> &nodes;
-    uint32_t levels = 0;  // inner nodes on the deepest root-to-leaf path = stack levels the traversal needs
-    Builder(std::vector<uint32_t> &p, std::vector<DevBvhNode> &n) : prims(p), nodes(n) {}
+    explicit Builder(std::vector<uint32_t> &p) : prims(p) {}
 
     static constexpr int BINS = 16;
+    // subtrees of at least PAR_MIN primitives in the first PAR_DEPTH levels are built by their own thread (they work on
+    // disjoint ranges of `prims`); the node order — parent, left subtree, right subtree — and hence the tree is the same
+    // as that of the serial build
+    static constexpr uint32_t PAR_MIN = 1u << 15;
+#ifdef RT_BVH_SERIAL
+    static constexpr int PAR_DEPTH = 0;
+#else
+    static constexpr int PAR_DEPTH = 5;
+#endif
 
-    // returns the reference of the subtree over prims[begin, end) and its box
-    uint32_t build(uint32_t begin, uint32_t end, int depth, Box &b) {
+    static void append_subtree(std::vector<DevBvhNode> &nodes, const std::vector<DevBvhNode> &sub, uint32_t &ref) {
+        const uint32_t offset = uint32_t(nodes.size());
+        for (DevBvhNode nd : sub) {
+            if (!(nd.ref0 & RT_BVH_LEAF_BIT)) nd.ref0 += offset;
+            if (!(nd.ref1 & RT_BVH_LEAF_BIT)) nd.ref1 += offset;
+            nodes.push_back(nd);
+        }
+        if (!(ref & RT_BVH_LEAF_BIT)) ref += offset;
+    }
+
+    // Appends the subtree over prims[begin, end) to `nodes` (node indices are positions in `nodes`) and returns its reference
+    // and box. `levels`: inner nodes on the deepest root-to-leaf path = stack levels the traversal needs.
+    uint32_t build(uint32_t begin, uint32_t end, int depth, Box &b, std::vector<DevBvhNode> &nodes, uint32_t &levels) {
         Box cb;
         b.reset(), cb.reset();
         for (uint32_t i = begin; i < end; i++) {
@@ -125,8 +145,26 @@ struct Builder {
             });
         }
         Box lb, rb;
-        const uint32_t lref = build(begin, mid, depth + 1, lb);
-        const uint32_t rref = build(mid, end, depth + 1, rb);
+        uint32_t lref, rref;
+        if (depth < PAR_DEPTH && n >= 2 * PAR_MIN) {
+            std::vector<DevBvhNode> lnodes, rnodes;
+            uint32_t llev = 0, rlev = 0;
+            std::future<uint32_t> left;
+            bool spawned = true;
+            try {
+                left = std::async(std::launch::async, [&] { return build(begin, mid, depth + 1, lb, lnodes, llev); });
+            } catch (const std::system_error &) {
+                spawned = false;  // no thread to be had: build it here
+            }
+            rref = build(mid, end, depth + 1, rb, rnodes, rlev);
+            lref = spawned ? left.get() : build(begin, mid, depth + 1, lb, lnodes, llev);
+            append_subtree(nodes, lnodes, lref);
+            append_subtree(nodes, rnodes, rref);
+            levels = std::max(levels, std::max(llev, rlev));
+        } else {
+            lref = build(begin, mid, depth + 1, lb, nodes, levels);
+            rref = build(mid, end, depth + 1, rb, nodes, levels);
+        }
         DevBvhNode &nd = nodes[me];
         for (int k = 0; k < 3; k++) nd.lo0[k] = lb.lo[k], nd.hi0[k] = lb.hi[k], nd.lo1[k] = rb.lo[k], nd.hi1[k] = rb.hi[k];
         nd.ref0 = lref, nd.ref1 = rref, nd._pad0 = nd._pad1 = 0;
@@ -144,7 +182,7 @@ uint32_t rt_build_bvh(const rthip_scene_desc *s, std::vector<DevBvhNode> &nodes,
     prims.clear();
     const size_t ns = s->n_spheres, nt = s->n_triangles, n = ns + nt;
     if (n == 0) return 0;
-    Builder B(prims, nodes);
+    Builder B(prims);
     B.pbox.resize(n);
     B.centroid.resize(3 * n);
     for (size_t i = 0; i < ns; i++) {
@@ -177,7 +215,8 @@ uint32_t rt_build_bvh(const rthip_scene_desc *s, std::vector<DevBvhNode> &nodes,
     std::iota(prims.begin(), prims.end(), 0u);
     nodes.reserve(n / 2 + 16);
     Box root;
-    const uint32_t ref = B.build(0, uint32_t(n), 0, root);
+    uint32_t levels = 0;
+    const uint32_t ref = B.build(0, uint32_t(n), 0, root, nodes, levels);
     if (ref & RT_BVH_LEAF_BIT) {
         // a single leaf: give it a root node whose second child is an empty (inverted, never hit) box
         DevBvhNode nd;
@@ -186,5 +225,5 @@ uint32_t rt_build_bvh(const rthip_scene_desc *s, std::vector<DevBvhNode> &nodes,
         nodes.push_back(nd);
         return 1;
     }
-    return B.levels;
+    return levels;
 }

@@ -128,6 +128,14 @@ int main(int argc, char **argv) {
     }
     if (c.max_levels != levels) return fail("reported stack levels != tree depth", levels, c.max_levels);
     if (levels > RT_BVH_MAX_DEPTH) return fail("deeper than the traversal stack", levels);
-    std::printf("OK nodes %zu levels %u\n", nodes.size(), levels);
+    // FNV-1a over the node and primitive arrays: the threaded build must give the tree of the serial one
+    uint64_t hsh = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t bytes) {
+        const unsigned char *c = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < bytes; i++) hsh = (hsh ^ c[i]) * 1099511628211ull;
+    };
+    mix(nodes.data(), nodes.size() * sizeof(DevBvhNode));
+    mix(prims.data(), prims.size() * sizeof(uint32_t));
+    std::printf("OK nodes %zu levels %u hash %016llx\n", nodes.size(), levels, (unsigned long long)hsh);
     return 0;
 }
