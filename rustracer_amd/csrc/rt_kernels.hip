@@ -1,23 +1,31 @@
 // rt_kernels.hip — gfx950 (CDNA4, wave64) kernels of the rustracer render path.
 //
-// One lane owns one pixel; a wave owns an 8x8 pixel tile (coherent primary rays => coherent
-// branches), a 256-thread workgroup a 16x16 tile. The recursion of Ray::_project_ray
-// (raytracer_core/src/shapes/ray.rs:69-87) is an iterative bounce loop with the path state
-// (ray, throughput, bounce count) in VGPRs, and the `samples` loop of generate_pixel
-// (lib.rs:281-288) is folded into the same loop by path regeneration: a lane whose path ended
-// starts its pixel's next sample at once, so a wave only idles lanes at the very end of a tile.
+// render_kernel<STATS, MODE, LIGHTS>: a 256-thread workgroup = a 16x16 pixel tile, a wave = an 8x8 tile (coherent primary
+// rays => coherent branches). The recursion of Ray::_project_ray (raytracer_core/src/shapes/ray.rs:69-87) is an iterative
+// bounce loop with the path state (ray, throughput, bounce count, RNG counter) in VGPRs, and the `samples` loop of
+// generate_pixel (lib.rs:281-288) is folded into the same loop by path regeneration.
+//   MODE_LDS    (<= 256 spheres): lane = pixel. Sphere geometry and a merged per-sphere shading record are staged in LDS once
+//               per workgroup and read back with wave-uniform (broadcast) ds_read_b128, so the closest-hit scan of
+//               ray.rs:47-67 runs on VGPR operands; a sphere that no lane of the wave can hit is dropped after its
+//               discriminant (wave-level early-out).
+//   MODE_BVH    (big scenes, extension): 64-byte two-box nodes, leaf-ordered primitive records, a resumable while-while
+//               traversal that yields when enough lanes have finished, and a per-wave pool of (pixel, sample) work items
+//               so that finished lanes take new work instead of idling (bvh_run, render_kernel POOL).
+//   MODE_GLOBAL (RTHIP_F_NO_BVH or > 256 spheres without a tree): the same linear scan from global memory, scalar loads.
+// resolve_kernel: second half of a sample-sliced launch (small launches are split into groups of 64 samples per workgroup so
+// that they fill the GPU to their end; the sums are grouped the same way when a launch is not sliced, so the image does not
+// depend on it). compact_kernel: work-list of the pixels that are not yet Final (RTHIP_F_ADAPTIVE, lib.rs:276-313).
+// pick_kernel: Raytracer::get_shape (lib.rs:262-267).
 //
-// The kernel is VALU-issue bound (profiles/): what matters is the instruction count per segment
-// and the instruction class (measured on MI355X, tools/ubench/valu_rates.hip: VGPR-only VOP2
-// ~2.6-2.9 cycles per wave instruction, anything with an SGPR operand / VOP3-only / compare ~4.4,
-// transcendental ~8.5). Hence:
-//   * small scenes (MODE_LDS): sphere geometry and a merged per-sphere shading record are staged in
-//     LDS once per workgroup and read back with wave-uniform (broadcast) ds_read_b128, so the
-//     closest-hit scan of ray.rs:47-67 runs on VGPR operands;
-//   * the ray direction is kept NORMALISED with its length on the side (the reference's t is in
-//     units of the un-normalised direction: the window (T_MIN, T_MAX) is scaled by |d| instead);
-//     this removes a = d.d, the 1/a multiplies and every later normalize();
-//   * Lambertian and Metal share one random unit vector / one RNG hash per bounce.
+// The scan kernels are VALU-issue bound (profiles/): what matters is the instruction count per segment and the instruction
+// class (measured on MI355X, tools/ubench/valu_rates.hip: VGPR-only VOP2 ~2.6-2.9 cycles per wave instruction, anything with
+// an SGPR operand / VOP3-only / compare ~4.4, transcendental ~8.5). Hence:
+//   * the ray direction is kept NORMALISED with its length on the side (the reference's t is in units of the un-normalised
+//     direction: the window (T_MIN, T_MAX) is scaled by |d| instead); this removes a = d.d, the 1/a multiplies and every
+//     later normalize();
+//   * Lambertian and Metal share one random unit vector, and the scattered ray of a continuing lane shares its RNG hash and
+//     its normalisation with the primary ray of a lane that starts a new sample (shade / next_ray);
+//   * radiance is handed over where a path ends (emit), not through a merged return value.
 // No MFMA: there is no dense contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 
