@@ -72,8 +72,7 @@ def main():
         torch.cuda.synchronize()
 
     def step(seed):
-        br.render(args.spp, MAX_DEPTH, 0, seed)
-        return br.gather()
+        return br.step(args.spp, MAX_DEPTH, 0, seed)  # render on this stream + gather on a side stream (overlaps the next render)
 
     for w in range(args.warmup):
         step(1000 + w)
@@ -83,9 +82,9 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev0[k].record()  # HIP events on the stream the kernel is launched on (torch's current stream)
-        br.render(args.spp, MAX_DEPTH, 0, k)
+        img = br.step(args.spp, MAX_DEPTH, 0, k)
         ev1[k].record()
-        img = br.gather()
+    br.wait()
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(1, args.steps)

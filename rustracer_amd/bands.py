@@ -100,8 +100,13 @@ class BandRenderer:
         self.rows = owned_rows(p)
         assert self.rows == len(owned_row_indices(self.height, band_rows if world > 1 else 0, rank, world))
         dev = torch.device("cuda", torch.cuda.current_device())
-        self.rgba = torch.empty((self.rows, self.width, 4), dtype=torch.uint8, device=dev)
+        # two frame buffers: the gather of frame k (on a side stream) overlaps the render of frame k + 1
+        self._bufs = [torch.empty((self.rows, self.width, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.rgba = self._bufs[0]
         self._gatherer = None if world == 1 else RowGatherer(self.height, band_rows, rank, world, (self.width, 4), torch.uint8, dev)
+        self._gather_stream = None if world == 1 else torch.cuda.Stream(device=dev)
+        self._gathered = [None, None]  # per buffer: event "the gather that read it has finished"
+        self._frame = 0
 
     def params(self, spp, max_depth, flags, seed=None):
         if self.world == 1:
@@ -114,6 +119,39 @@ class BandRenderer:
         stream = self.torch.cuda.current_stream().cuda_stream
         return self.rt.render_device(self.params(spp, max_depth, flags, seed), self.rgba.data_ptr(), 0, stream, want_stats)
 
+    def step(self, spp, max_depth=50, flags=0, seed=None, group=None, force_collective=False):
+        """One frame, pipelined: render this rank's bands on torch's current stream into one of two buffers and start the
+        gather to rank 0 on a side stream, so that it overlaps the next frame's render. Returns the frame on rank 0 (None
+        elsewhere); call wait() before reading it. force_collective: run the gather also when world == 1 (tests)."""
+        torch = self.torch
+        k = self._frame & 1
+        self._frame += 1
+        buf = self._bufs[k]
+        main = torch.cuda.current_stream()
+        if self._gathered[k] is not None:
+            main.wait_event(self._gathered[k])  # the gather of two frames ago has finished reading this buffer
+        self.rt.render_device(self.params(spp, max_depth, flags, seed), buf.data_ptr(), 0, main.cuda_stream, False)
+        self.rgba = buf
+        if self._gatherer is None and not force_collective:
+            return buf
+        if self._gatherer is None:
+            self._gatherer = RowGatherer(self.height, self.band_rows, self.rank, self.world, (self.width, 4), torch.uint8, buf.device)
+            self._gather_stream = torch.cuda.Stream(device=buf.device)
+        rendered = torch.cuda.Event()
+        rendered.record(main)
+        with torch.cuda.stream(self._gather_stream):
+            self._gather_stream.wait_event(rendered)
+            full = self._gatherer(buf, group)
+            done = torch.cuda.Event()
+            done.record(self._gather_stream)
+        self._gathered[k] = done
+        return full
+
+    def wait(self):
+        """make torch's current stream wait for the gathers started by step()"""
+        if self._gather_stream is not None:
+            self.torch.cuda.current_stream().wait_stream(self._gather_stream)
+
     def gather(self, group=None):
-        """the frame on rank 0 (a view of a buffer that the next gather overwrites), None elsewhere"""
+        """(unpipelined) the frame on rank 0 (a view of a buffer that the next gather overwrites), None elsewhere"""
         return self.rgba if self._gatherer is None else self._gatherer(self.rgba, group)

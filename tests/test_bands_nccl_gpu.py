@@ -37,6 +37,28 @@ def test_band_renderer_through_rccl_world1():
             torch.cuda.synchronize()
             assert full.shape == (h, w, 4)
             assert np.array_equal(full.cpu().numpy(), want), f"frame {frame}"
+        # the pipelined form bench.py uses: double-buffered frames, gather on a side stream overlapping the next render
+        seeds = [11, 12, 13, 14, 15]
+        wants = []
+        for sd in seeds:
+            rt.seed = sd
+            wants.append(rt.render(flat, spp, max_depth=depth, want_accum=False).rgba8)
+        br2 = BandRenderer(rt, 0, 1, 8)
+        frames = []
+        for sd in seeds:
+            full = br2.step(spp, depth, 0, sd, force_collective=True)
+            frames.append(full.clone())   # enqueued on the current stream: must not see the next frame's bytes...
+            br2.wait()                    # ...which is what wait() orders
+            frames[-1] = full.clone()
+        torch.cuda.synchronize()
+        for sd, got, want in zip(seeds, frames, wants):
+            assert np.array_equal(got.cpu().numpy(), want), f"pipelined frame seed {sd}"
+        # without intermediate waits the LAST frame must still be complete after wait()
+        for sd in seeds:
+            full = br2.step(spp, depth, 0, sd, force_collective=True)
+        br2.wait()
+        torch.cuda.synchronize()
+        assert np.array_equal(full.cpu().numpy(), wants[-1])
         t = torch.tensor([1.5, 2.5], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert t.tolist() == [1.5, 2.5]
