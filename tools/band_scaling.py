@@ -10,8 +10,9 @@ rt.render(flat, SPP, max_depth=DEPTH, want_accum=False)
 base = min(rt.render(flat, SPP, max_depth=DEPTH, want_accum=False).stats["kernel_ms"] for _ in range(3))
 print(f"world 1: {base:.3f} ms")
 for world in (2, 4, 8):
-    worst = 0.0
+    times = []
     for rank in range(world):
-        t = min(rt.render(flat, SPP, max_depth=DEPTH, want_accum=False, band_rows=8, band_first=rank, band_stride=world).stats["kernel_ms"] for _ in range(3))
-        worst = max(worst, t)
-    print(f"world {world}: slowest rank {worst:.3f} ms, ideal {base / world:.3f} ms, kernel scaling efficiency {base / world / worst * 100:.1f} %")
+        times.append(min(rt.render(flat, SPP, max_depth=DEPTH, want_accum=False, band_rows=8, band_first=rank, band_stride=world).stats["kernel_ms"] for _ in range(3)))
+    worst = max(times)
+    print(f"world {world}: slowest rank {worst:.3f} ms, mean {sum(times) / world:.3f} ms, ideal {base / world:.3f} ms, kernel scaling efficiency {base / world / worst * 100:.1f} %"
+          f"  per rank: {' '.join(f'{t:.2f}' for t in times)}")
