@@ -16,7 +16,7 @@
 #include <stdint.h>
 
 #define RT_LDS_SPHERES 256u
-#define RT_CHUNK_BVH 8u
+#define RT_CHUNK_BVH 4u
 // samples per slice: 64, doubled until at most 16 slices cover spp; a function of spp alone, always a power of two
 #ifndef RT_SLICE_SPP
 #define RT_SLICE_SPP 64u
