@@ -482,7 +482,7 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 // [MODE_BVH: bvh_levels x 256 x 4 traversal stack | 4 waves x 64 x 16 per-pixel {base direction, RNG key}
 // | 4 waves x 3 x 64*chunk x 4 radiance slots]; rt_launch_render computes the size.
 template <bool STATS, int MODE, bool LIGHTS>
-__global__ __launch_bounds__(256, (LIGHTS || STATS) ? 4 : (MODE == MODE_BVH ? 5 : 7)) void render_kernel(const KernelParams P) {
+__global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 5) : (MODE == MODE_BVH ? 5 : 7))) void render_kernel(const KernelParams P) {
     constexpr bool POOL = MODE == MODE_BVH;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     rt_f4 *s_geom_mem = (rt_f4 *)s_dyn;
