@@ -479,7 +479,7 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 //    idle lanes come from divergent shading branches, not from unequal pixels — hence not used there.)
 //
 // Dynamic LDS layout (bytes): [MODE_LDS: RT_LDS_SPHERES x 16 geometry | 3 x n_spheres x 16 shading]
-// [MODE_BVH: bvh_levels x 256 x 4 traversal stack | 4 waves x 64 x 16 per-pixel {base direction, RNG key}
+// [MODE_BVH: bvh_levels x 256 x 4 traversal stack | 4 waves x 64 x 8 per-pixel {RNG key, x | y << 16}
 // | 4 waves x 3 x 64*chunk x 4 radiance slots]; rt_launch_render computes the size.
 template <bool STATS, int MODE, bool LIGHTS>
 __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 5) : (MODE == MODE_BVH ? 5 : 7))) void render_kernel(const KernelParams P) {
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 
     rt_f4 *s_geom_mem = (rt_f4 *)s_dyn;
     rt_f4 *s_shade_mem = s_geom_mem + (MODE == MODE_LDS ? RT_LDS_SPHERES : 0u);  // fixed offsets: folded into the ds_read offset field
     uint32_t *s_stack = (uint32_t *)(s_shade_mem + (MODE == MODE_LDS ? 3u * P.n_spheres : 0u));
-    rt_f4 *s_pix_all = (rt_f4 *)(s_stack + (MODE == MODE_BVH ? P.bvh_levels * 256u : 0u));
+    uint2 *s_pix_all = (uint2 *)(s_stack + (MODE == MODE_BVH ? P.bvh_levels * 256u : 0u));  // per pixel {RNG key, x | y << 16}
     float *s_L_all = (float *)(s_pix_all + 256);
     const rt_f4 *s_geom = s_geom_mem;
     if (MODE == MODE_LDS) {
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 
     for (int i = 0; i < RT_STAT_N; i++) cnt[i] = 0;
 
     if (amask != 0ull) {
-        rt_f4 *s_pix = s_pix_all + (wave << 6);
+        uint2 *s_pix = s_pix_all + (wave << 6);
         const uint32_t plane = P.chunk << 6;  // floats per colour plane of the wave's radiance slots
         float *s_L = s_L_all + wave * 3u * plane;
         rt_f4 pp_own;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 
             pp.y = fmaf(P.vy, pv, fmaf(P.hy, pu, P.d00y));
             pp.z = fmaf(P.vz, pv, fmaf(P.hz, pu, P.d00z));
             pp.w = __uint_as_float(rt_pixel_key(rt_seed_key(P.seed), y * P.width + x));
-            if (POOL) s_pix[lane] = pp;
+            if (POOL) s_pix[lane] = make_uint2(__float_as_uint(pp.w), x | (y << 16));
             pp_own = pp;
         }
         const f3 cam_o = mk3(P.ox, P.oy, P.oz);
@@ -749,8 +749,14 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 
             uint32_t k = key + RT_RNG_GOLDEN;  // RNG slot 1 + bounce
             if (POOL) {
                 if (fresh) {
-                    pp = s_pix[pixel];
-                    k = rt_counter(__float_as_uint(pp.w), sample, 0);
+                    // the pixel's key and coordinates (8 B of LDS per pixel); its base direction is recomputed: 10 instructions
+                    // per path are nothing next to a traversal, and 2 KB of LDS per workgroup are an extra workgroup per CU
+                    const uint2 px = s_pix[pixel];
+                    const float pu = float(px.y & 0xffffu) * P.inv_wm1, pv = float(px.y >> 16) * P.inv_hm1;
+                    pp.x = fmaf(P.vx, pv, fmaf(P.hx, pu, P.d00x));
+                    pp.y = fmaf(P.vy, pv, fmaf(P.hy, pu, P.d00y));
+                    pp.z = fmaf(P.vz, pv, fmaf(P.hz, pu, P.d00z));
+                    k = rt_counter(px.x, sample, 0);
                 }
             } else {
                 k = fresh ? key_own : k;
@@ -1061,7 +1067,7 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
         if (P.bvh_levels == 0 || P.bvh_levels > RT_BVH_MAX_DEPTH) return hipErrorInvalidValue;
         P.chunk = default_chunk();
         if (P.chunk > P.spp) P.chunk = P.spp;
-        lds = P.bvh_levels * 1024u + 4096u + 4u * 3u * 64u * 4u * P.chunk;
+        lds = P.bvh_levels * 1024u + 2048u + 4u * 3u * 64u * 4u * P.chunk;
     } else {
         P.chunk = P.spp;  // lane = pixel: one "chunk", no radiance slots
         P.bvh_levels = 0;
