@@ -247,3 +247,30 @@ def test_adaptive_rule_in_the_oracle(oracle_mod, default_camera, standalone_flat
     assert (emu.status == FINAL).any() and emu.live().any()
     froze_at = state.nb_samples[emu.status == FINAL]
     assert froze_at.min() >= 5 * spp and froze_at.max() <= 12 * spp
+
+
+def _lambert_plateau_scene():
+    from rustracer_amd import Lambertian, Sphere, flatten
+    # a sphere so large that the part in view is a horizontal plateau (normal = +y to 3e-3): convex, so every path is
+    # camera -> ground -> sky, and L = albedo/pi*3 * E[sky(d)] with d = normalize(n + w) cosine-distributed about n
+    return flatten([Sphere.new((0.0, -1000.0, -1.0), 1000.0, Lambertian.new((0.9, 0.5, 0.25)))])
+
+
+def lambert_plateau_expected():
+    # E[d.y] = 2/3 for a cosine-weighted hemisphere about +y  =>  E[t] = 0.5 (2/3 + 1) = 5/6 in background_color (ray.rs:89-93):
+    # E[sky] = (1 - 5/6) (1,1,1) + 5/6 (0.5, 0.7, 1.0); throughput = albedo / pi * 3 (lambertian_diffuse.rs:21,60-65)
+    sky = (1.0 - 5.0 / 6.0) * np.ones(3) + 5.0 / 6.0 * np.array([0.5, 0.7, 1.0])
+    return np.array([0.9, 0.5, 0.25]) / np.pi * 3.0 * sky
+
+
+def test_lambert_sky_integral_closed_form(oracle_mod, default_camera):
+    """a statistical known-answer test of the whole path (jitter, hit, Lambertian bounce distribution, throughput, sky)"""
+    from rustracer_amd import make_params
+    w, h, spp = 64, 36, 512
+    flat = _lambert_plateau_scene()
+    _, acc, st, _ = oracle_mod.render(flat, default_camera, make_params(w, h, spp, 50, 77), precision=64)
+    patch = acc[2:12, 16:48] / spp              # ground pixels near the bottom of the frame
+    got = patch.reshape(-1, 3).mean(axis=0)
+    want = lambert_plateau_expected()
+    assert np.allclose(got, want, rtol=6e-3), (got, want)
+    assert st["rays"] >= st["paths"]

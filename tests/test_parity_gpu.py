@@ -413,3 +413,18 @@ def test_many_samples_sliced_vs_oracle(oracle_mod, default_camera, standalone_fl
     assert np.allclose(res.accum / spp, acc / spp, atol=4e-3)
     print(f"\n2050 spp: {describe(hist, ok)}; max |mean radiance delta| {np.abs(res.accum / spp - acc / spp).max():.2e}")
     rt.close()
+
+
+def test_lambert_sky_integral_closed_form():
+    """the device against a closed-form expectation (not the oracle): E[L] = albedo/pi*3 * E[sky] for a Lambertian plateau"""
+    from test_oracle_kat import _lambert_plateau_scene, lambert_plateau_expected
+    w, h, spp = 128, 72, 1024
+    rt = Raytracer.new(w, h, seed=77)
+    res = rt.render(_lambert_plateau_scene(), spp, max_depth=50, flags=abi.F_COUNT_STATS)
+    got = (res.accum[4:24, 32:96] / spp).reshape(-1, 3).mean(axis=0)
+    want = lambert_plateau_expected()
+    print(f"\nLambertian plateau: device mean radiance {got}, closed form {want}")
+    assert np.allclose(got, want, rtol=3e-3)
+    # every ground path is exactly two segments (convex surface): camera -> ground -> sky
+    assert res.stats["hits"][abi.MAT_LAMBERTIAN] + res.stats["paths"] == res.stats["rays"]
+    rt.close()
