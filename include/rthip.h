@@ -184,8 +184,9 @@ int rthip_device_count(int *out_count);
 /* Create a context on `device`. Replaces Raytracer::new (lib.rs:250). */
 int rthip_create(int device, rthip_ctx **out_ctx);
 
-/* Flatten the scene to device SoA buffers (and a linear BVH for big scenes).
- * Replaces the borrowed `&[Box<dyn Shape>]` argument of generate_pixel (lib.rs:272). */
+/* Flatten the scene to device SoA buffers (and a BVH for scenes of more than 64 spheres + triangles).
+ * Replaces the borrowed `&[Box<dyn Shape>]` argument of generate_pixel (lib.rs:272). Waits for every pass still running
+ * on the device (also those enqueued on caller streams by rthip_render_device) before touching the scene buffers. */
 int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *scene);
 
 /* Replaces the `pub camera: Camera` field (lib.rs:240) read by emit_ray_at (camera.rs:43-50).

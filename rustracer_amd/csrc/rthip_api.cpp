@@ -298,7 +298,8 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
                 return fail(ctx, RTHIP_E_BADARG, "triangle " + std::to_string(i) + ": non-finite vertex");
         }
         HIPCHK(ctx, hipSetDevice(ctx->device));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        // passes enqueued by rthip_render_device on the CALLER's streams may still be reading the scene buffers
+        HIPCHK(ctx, hipDeviceSynchronize());
         ctx->have_scene = false;
         const double PI = 3.14159265358979323846264338327950288;
 
