@@ -148,7 +148,7 @@ enum { RTHIP_STATUS_NOT_STARTED = 0, RTHIP_STATUS_COPY_NEAR_PIXEL = 1 /* never p
 typedef struct rthip_render_params {
     uint32_t width;       /* full image width  (u = (x+xi)/(width-1),  lib.rs:282-283) */
     uint32_t height;      /* full image height (v = (y+xi)/(height-1), lib.rs:284-285) */
-    uint32_t spp;         /* samples per pixel of THIS pass (generate_pixel's `samples`) */
+    uint32_t spp;         /* samples per pixel of THIS pass (generate_pixel's `samples`); a running sum holds at most 2^24 */
     uint32_t max_depth;   /* 50 = reference (ray.rs:44) */
     uint32_t seed;        /* counter-RNG seed (replaces the entropy-seeded SmallRng) */
     uint32_t flags;       /* RTHIP_F_* */

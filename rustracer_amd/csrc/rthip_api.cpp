@@ -500,7 +500,8 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rg
         if (accumulate && adaptive != ctx->adaptive)
             return fail(ctx, RTHIP_E_STATE, "RTHIP_F_ADAPTIVE must be set on every pass of a running sum or on none (Final pixels stop accumulating)");
         const uint64_t prior = accumulate ? ctx->nb_samples : 0;
-        if (prior + p->spp > 0xffffffffull) return fail(ctx, RTHIP_E_BADARG, "more than 2^32 samples per pixel");
+        // the RNG counter of (sample, slot) is sample*256 + slot in 32 bits (rt_rng.h): the sample streams would repeat beyond 2^24
+        if (prior + p->spp > (1ull << 24)) return fail(ctx, RTHIP_E_BADARG, "more than 2^24 samples per pixel");
         if (rows == 0) {
             if (stats) std::memset(stats, 0, sizeof *stats);
             return RTHIP_OK;

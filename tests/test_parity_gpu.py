@@ -294,6 +294,9 @@ def test_error_behaviour():
     out = np.zeros((36, 64, 4), np.uint8)
     assert lib.rthip_render(ctx, C.byref(p), out.ctypes.data, None, None) == 0
     assert out[..., 3].min() == 255
+    # a running sum holds at most 2^24 samples per pixel (the RNG counter of a sample would wrap)
+    huge = make_params(64, 36, (1 << 24), flags=abi.F_ACCUMULATE)
+    assert lib.rthip_render(ctx, C.byref(huge), None, None, None) == abi.E_BADARG and b"2^24" in lib.rthip_last_error(ctx)
     lib.rthip_destroy(ctx)
 
 
