@@ -130,6 +130,7 @@ int validate_params(rthip_ctx *ctx, const rthip_render_params *p) {
     if (!p) return fail(ctx, RTHIP_E_BADARG, "params is NULL");
     if (p->width < 2 || p->height < 2) return fail(ctx, RTHIP_E_BADARG, "width and height must be >= 2 (the jitter divides by width-1, height-1: lib.rs:283,285)");
     if (p->width > 65536 || p->height > 65536) return fail(ctx, RTHIP_E_BADARG, "width/height above 65536 are not supported");
+    if (uint64_t(p->width) * p->height > (1ull << 31)) return fail(ctx, RTHIP_E_BADARG, "more than 2^31 pixels are not supported (32-bit pixel indices)");
     if (p->spp == 0) return fail(ctx, RTHIP_E_BADARG, "spp must be >= 1");
     if (p->band_rows != 0 && p->band_stride == 0) return fail(ctx, RTHIP_E_BADARG, "band_stride must be >= 1 when band_rows != 0");
     if (p->flags & ~uint32_t(RTHIP_F_ACCUMULATE | RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_NO_BVH | RTHIP_F_ADAPTIVE))
