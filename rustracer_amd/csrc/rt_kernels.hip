@@ -815,6 +815,60 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 
             set_dir(nd);
         };
         if constexpr (!POOL) {
+            // ---- empty tiles: no ray of this wave's pixels can reach any shape => every path is "primary ray -> sky" -------
+            // Conservative test per lane and sphere, on the bundle of rays through the pixel's jitter square: every such ray d
+            // lies within the angle theta of the ray a through the square's centre, so if it hits sphere (c, r) at distance
+            // s <= |q| + r (q = c - o), the centre is within r + s*theta of the half-line o + s*a. theta is bounded from the
+            // square's corners with a factor pi/2 to spare, the right-hand side carries a relative margin 1e-4 (FP32: ~1e-6).
+            // The fast loop below evaluates exactly the expressions of next_ray(fresh) + shade() for a miss: same bits.
+            bool tile_empty = false;
+            if (!STATS && !LIGHTS && MODE == MODE_LDS && P.n_planes == 0 && P.n_tris == 0 && P.max_depth != 0) {
+                const f3 hw = mk3(P.hx * P.inv_wm1, P.hy * P.inv_wm1, P.hz * P.inv_wm1), vh = mk3(P.vx * P.inv_hm1, P.vy * P.inv_hm1, P.vz * P.inv_hm1);
+                const f3 e00 = mk3(pp_own.x, pp_own.y, pp_own.z), e10 = e00 + hw, e01 = e00 + vh, e11 = e10 + vh;
+                const f3 ec = e00 + (hw + vh) * 0.5f;
+                const float lc = fast_sqrt(dot(ec, ec));
+                const f3 a = ec * fast_rcp(lc);
+                const f3 d0 = e00 - ec, d1 = e10 - ec, d2 = e01 - ec, d3 = e11 - ec;
+                const float dev = fast_sqrt(fmaxf(fmaxf(dot(d0, d0), dot(d1, d1)), fmaxf(dot(d2, d2), dot(d3, d3))));
+                const float lmin = fast_sqrt(fminf(fminf(dot(e00, e00), dot(e10, e10)), fminf(dot(e01, e01), dot(e11, e11))));
+                const float theta = 1.6f * dev * fast_rcp(lmin);  // >= the angle between a and any ray of the bundle (sin x >= 2x/pi)
+                bool can_hit = !(theta < 0.5f);                   // a degenerate camera (NaN, huge pixels): no fast path
+                for (uint32_t i = 0; i < P.n_spheres; i++) {
+                    const rt_f4 g = s_geom[i];
+                    const f3 q = mk3(g.x - cam_o.x, g.y - cam_o.y, g.z - cam_o.z);
+                    const float rad = fast_sqrt(g.w), lq = fast_sqrt(dot(q, q));
+                    const f3 qa = cross(q, a);
+                    const float dist = (dot(q, a) >= 0.0f) ? fast_sqrt(dot(qa, qa)) : lq;
+                    const float reach = fmaf(lq + rad, theta, rad) * 1.0001f + 1e-30f;
+                    can_hit |= !(dist > reach);  // NaN => can hit
+                }
+                tile_empty = __ballot(active && can_hit) == 0ull;
+            }
+            if (tile_empty) {
+                if (active) {
+                    const uint32_t g_mask = P.slice_spp - 1u;
+                    uint32_t k = rt_counter(__float_as_uint(pp_own.w), P.sample0 + s_first, 0);
+                    for (uint32_t s = 1; s <= n_spp; s++) {
+                        const uint32_t hb = rt_mix32(k);
+                        k += RT_RNG_SLOTS * RT_RNG_GOLDEN;
+                        const float ju = rt_unit(hb) * P.inv_wm1, jv = rt_unit(rt_second(hb)) * P.inv_hm1;  // lib.rs:282-285
+                        const f3 nd = mk3(fmaf(P.vx, jv, fmaf(P.hx, ju, pp_own.x)), fmaf(P.vy, jv, fmaf(P.hy, ju, pp_own.y)), fmaf(P.vz, jv, fmaf(P.hz, ju, pp_own.z)));
+                        const float dy = nd.y * fast_rsq(dot(nd, nd));
+                        const float t = fmaf(0.5f, dy, 0.5f);  // background_color, ray.rs:89-93
+                        const float w = 1.0f - t;
+                        f3 L = mk3(fmaf(0.5f, t, w), fmaf(0.7f, t, w), w + t);
+                        asm volatile("" : "+v"(L.x), "+v"(L.y), "+v"(L.z));
+                        grp = grp + L;
+                        if ((s & g_mask) == 0u && s != n_spp) {
+                            acc = acc + grp;
+                            grp = mk3(0.0f, 0.0f, 0.0f);
+                        }
+                    }
+                    acc = acc + grp;
+                    cnt[RT_STAT_PATHS] += n_spp;
+                    cnt[RT_STAT_RAYS] += n_spp;
+                }
+            } else
             // ---- lane = pixel: path regeneration over the pixel's samples ----
             if (active) {
                 uint32_t s_done = 0;

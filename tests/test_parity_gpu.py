@@ -431,3 +431,36 @@ def test_lambert_sky_integral_closed_form():
     # every ground path is exactly two segments (convex surface): camera -> ground -> sky
     assert res.stats["hits"][abi.MAT_LAMBERTIAN] + res.stats["paths"] == res.stats["rays"]
     rt.close()
+
+
+def test_empty_tile_fast_path_is_exact(standalone_flat):
+    """waves whose pixels cannot reach any sphere skip the scene query (conservative cone test per pixel). The instrumented
+    kernel has no such path: both must give the same bits — on the standalone frame and on random scenes of small spheres
+    whose silhouettes cross many tiles, including spheres behind the camera and one around it."""
+    from rustracer_amd import Metal
+    rt = Raytracer.new(3840, 2160, seed=4)
+    a = rt.render(standalone_flat, 3, max_depth=5)
+    b = rt.render(standalone_flat, 3, max_depth=5, flags=abi.F_COUNT_STATS)
+    assert np.array_equal(a.accum, b.accum) and np.array_equal(a.rgba8, b.rgba8)
+    assert a.stats["rays"] == b.stats["rays"] and a.stats["paths"] == b.stats["paths"]
+    rt.close()
+    rng = np.random.default_rng(5)
+    w, h = 640, 360
+    rt = Raytracer.new(w, h, seed=6)
+    n_sky_only = 0
+    for trial in range(24):
+        n = int(rng.integers(1, 9))
+        scene = []
+        for _ in range(n):
+            c = rng.uniform(-4, 4, 3) + np.array([0.0, 0.0, -3.0])
+            scene.append(Sphere.new(c, float(rng.choice([0.01, 0.05, 0.3, 1.0])), Metal.new((0.8, 0.8, 0.8), 0.0)))
+        if trial % 6 == 5:
+            scene.append(Sphere.new((-1.8, 1.0, 2.0), 0.5, Lambertian.new((0.5, 0.5, 0.5))))   # the camera sits inside this one
+        flat = flatten(scene)
+        a = rt.render(flat, 2, max_depth=4)
+        b = rt.render(flat, 2, max_depth=4, flags=abi.F_COUNT_STATS)
+        assert np.array_equal(a.accum, b.accum), f"trial {trial}: {(a.accum != b.accum).any(axis=2).sum()} pixels differ"
+        assert a.stats["rays"] == b.stats["rays"]
+        n_sky_only += int(b.stats["rays"] == b.stats["paths"])
+    assert n_sky_only < 24   # the scenes do put spheres in view
+    rt.close()
