@@ -497,27 +497,31 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 
         __syncthreads();
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    // Sample slicing (strong scaling): blockIdx.y traces samples [slice*slice_spp, ...) of its pixels, so that a workgroup
+    // Sample slicing (strong scaling): a workgroup traces samples [slice*slice_spp, ...) of its pixels, so that a workgroup
     // lives for at most slice_spp samples however large spp is — with one workgroup per tile for all 256 spp, the last
     // workgroups of a 1/8-frame launch ran for a third of the kernel on a mostly idle GPU (73 % kernel efficiency at 8 GPUs).
     // Whether a launch is sliced is a scheduling decision (rt_launch_render: only when the grid is too small to fill the
     // GPU otherwise); the IMAGE does not depend on it, because the unsliced kernel adds the samples in the same groups:
     // sum = (...((g0 + g1) + g2)...), g_k = the sequential sum of samples [k*slice_spp, (k+1)*slice_spp).
     const bool sliced = P.n_slices > 1;
-    const uint32_t s_first = sliced ? blockIdx.y * P.slice_spp : 0u;
+    // the slice is the FAST index of the grid: the slices of a tile are scheduled together, so that the launch ends with the
+    // last (cheap, sky) tiles of the image rather than with the expensive tiles of its last slice
+    const uint32_t slice = sliced ? blockIdx.x % P.n_slices : 0u;
+    const uint32_t group = sliced ? blockIdx.x / P.n_slices : blockIdx.x;  // tile (or block of the work-list)
+    const uint32_t s_first = slice * P.slice_spp;
     const uint32_t n_spp = sliced ? min(P.slice_spp, P.spp - s_first) : P.spp;
     uint32_t x, lrow;
     bool listed = true;
     if (P.worklist) {
         // RTHIP_F_ADAPTIVE, pass >= 2: thread i traces the i-th pixel that is not yet Final (compact_kernel)
-        const uint32_t gi = blockIdx.x * 256u + threadIdx.x;
+        const uint32_t gi = group * 256u + threadIdx.x;
         listed = gi < *P.worklist_count;
         const uint32_t oi = listed ? P.worklist[gi] : 0u;
         lrow = oi / P.width;
         x = oi - lrow * P.width;
     } else {
         const uint32_t tiles_x = (P.width + 15u) >> 4;
-        const uint32_t tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+        const uint32_t tile_x = group % tiles_x, tile_y = group / tiles_x;
         x = (tile_x << 4) + ((wave & 1u) << 3) + (lane & 7u);
         lrow = (tile_y << 4) + ((wave >> 1) << 3) + (lane >> 3);
     }
@@ -945,7 +949,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 
             const size_t oi = size_t(lrow) * P.width + x;
             if (sliced) {
                 // sample slicing: this workgroup traced one slice of the pixel's samples; resolve_kernel adds the slices in order
-                float *part = P.partial + (size_t(blockIdx.y) * P.owned_rows * P.width + oi) * 3;
+                float *part = P.partial + (size_t(slice) * P.owned_rows * P.width + oi) * 3;
                 part[0] = acc.x, part[1] = acc.y, part[2] = acc.z;
             } else {
                 finish_pixel(P, oi, acc, cnt[RT_STAT_PIX_TRACED], cnt[RT_STAT_PIX_FINAL]);
@@ -1082,9 +1086,9 @@ __global__ void pick_kernel(const KernelParams P, float u, float v, long long *o
 template <bool STATS, int MODE>
 static void launch_variant(const KernelParams &P, bool lights, uint32_t blocks, uint32_t lds, hipStream_t stream) {
     if (lights)
-        hipLaunchKernelGGL((render_kernel<STATS, MODE, true>), dim3(blocks, P.n_slices), dim3(256), lds, stream, P);
+        hipLaunchKernelGGL((render_kernel<STATS, MODE, true>), dim3(blocks * P.n_slices), dim3(256), lds, stream, P);
     else
-        hipLaunchKernelGGL((render_kernel<STATS, MODE, false>), dim3(blocks, P.n_slices), dim3(256), lds, stream, P);
+        hipLaunchKernelGGL((render_kernel<STATS, MODE, false>), dim3(blocks * P.n_slices), dim3(256), lds, stream, P);
 }
 
 template <bool STATS>
