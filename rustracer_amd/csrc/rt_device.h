@@ -22,7 +22,9 @@
 #define RT_SLICE_SPP 64u
 #endif
 #define RT_MAX_SLICES 16u
-#define RT_SLICE_BELOW_BLOCKS 12000u /* launches of fewer workgroups than this are sliced */
+#ifndef RT_SLICE_BELOW_BLOCKS
+#define RT_SLICE_BELOW_BLOCKS 20000u
+#endif /* launches of fewer workgroups than this are sliced */
 #define RT_T_MIN 0.001f      /* raytracer_core/src/shapes/ray.rs:5 */
 #define RT_T_MAX 100000.0f   /* raytracer_core/src/shapes/ray.rs:6 */
 
