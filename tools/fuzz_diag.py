@@ -4,7 +4,7 @@ import numpy as np, oracle
 from fuzz_parity import random_scene
 from rustracer_amd import Raytracer, abi, flatten, make_params
 from rustracer_amd.scene import Camera
-for sd in (23, 45, 29):
+for sd in [int(a) for a in sys.argv[1:]] or (23, 45, 29):
     rng = np.random.default_rng(sd)
     shapes, lights, pose, flavour = random_scene(rng)
     w, h = int(rng.choice([33, 64, 97, 160])), int(rng.choice([17, 36, 55, 90]))
