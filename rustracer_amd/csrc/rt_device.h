@@ -57,7 +57,9 @@ struct DevLight { float px, py, pz, _p0, ir, ig, ib, _p1; };
 // record array bvh_recs (count <= RT_BVH_LEAF, first < 2^29).
 // bvh_recs: 3 x float4 per primitive, in leaf order (no index indirection):
 //   triangle {v0, global shape index} {e1, kind = 1} {e2, 0};  sphere {c, global shape index} {r*r, 0, 0, kind = 0} {0}
-#define RT_BVH_LEAF 4u
+#ifndef RT_BVH_LEAF
+#define RT_BVH_LEAF 2u
+#endif
 #ifndef RT_BVH_MAX_DEPTH
 #define RT_BVH_MAX_DEPTH 32
 #endif
