@@ -176,7 +176,7 @@ __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
     s.sp = 0;
 }
 #ifndef RT_BVH_LEAF_LANES
-#define RT_BVH_LEAF_LANES 28
+#define RT_BVH_LEAF_LANES 16
 #endif
 #ifndef RT_BVH_YIELD_LANES
 #define RT_BVH_YIELD_LANES 24
