@@ -227,3 +227,62 @@ uint32_t rt_build_bvh(const rthip_scene_desc *s, std::vector<DevBvhNode> &nodes,
     }
     return levels;
 }
+
+
+namespace {
+inline uint32_t f_bits(float x) { uint32_t u; std::memcpy(&u, &x, 4); return u; }
+inline float bits_f(uint32_t u) { float x; std::memcpy(&x, &u, 4); return x; }
+// the largest float <= x whose low 8 mantissa bits are zero
+inline float round_down_frame(float x) {
+    uint32_t u = f_bits(x);
+    if (!(u & 0x80000000u)) return bits_f(u & 0xffffff00u);   // positive: towards zero is down
+    if (u & 0xffu) u = (u | 0xffu) + 1u;                       // negative: away from zero
+    return bits_f(u);
+}
+}  // namespace
+
+double rt_bvh_dequantize(uint32_t frame, uint32_t q8) {
+    const double origin = double(bits_f(frame & 0xffffff00u));
+    const double step = std::ldexp(1.0, int(frame & 0xffu) - 127);
+    return origin + double(q8) * step;
+}
+
+bool rt_bvh_quantize(const std::vector<DevBvhNode> &nodes, std::vector<DevBvhNodeQ> &out) {
+    out.resize(nodes.size());
+    for (size_t i = 0; i < nodes.size(); i++) {
+        const DevBvhNode &n = nodes[i];
+        DevBvhNodeQ &q = out[i];
+        q.ref0 = n.ref0, q.ref1 = n.ref1;
+        const bool empty0 = n.lo0[0] > n.hi0[0], empty1 = n.lo1[0] > n.hi1[0];
+        for (int k = 0; k < 3; k++) {
+            float lo = INFINITY, hi = -INFINITY;
+            if (!empty0) lo = std::min(lo, n.lo0[k]), hi = std::max(hi, n.hi0[k]);
+            if (!empty1) lo = std::min(lo, n.lo1[k]), hi = std::max(hi, n.hi1[k]);
+            if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) return false;
+            const float origin = round_down_frame(lo);
+            if (!std::isfinite(origin) || origin > lo) return false;
+            const double extent = double(hi) - double(origin);
+            int e = 1;  // biased exponent of the step; >= 1 keeps the step a normal float
+            if (extent > 0.0) {
+                int ex;
+                std::frexp(extent / 255.0, &ex);   // extent / 255 = m * 2^ex, m in [0.5, 1)  =>  2^ex >= extent / 255
+                e = std::max(1, ex + 127);
+            }
+            while (e < 254 && 255.0 * std::ldexp(1.0, e - 127) < extent) e++;
+            if (255.0 * std::ldexp(1.0, e - 127) < extent) return false;
+            const double step = std::ldexp(1.0, e - 127);
+            const uint32_t frame = (f_bits(origin) & 0xffffff00u) | uint32_t(e);
+            auto qlo = [&](float v) { double t = std::floor((double(v) - double(origin)) / step); return uint32_t(std::min(255.0, std::max(0.0, t))); };
+            auto qhi = [&](float v) { double t = std::ceil((double(v) - double(origin)) / step); return uint32_t(std::min(255.0, std::max(0.0, t))); };
+            uint32_t l0 = 255, h0 = 0, l1 = 255, h1 = 0;
+            if (!empty0) l0 = qlo(n.lo0[k]), h0 = qhi(n.hi0[k]);
+            if (!empty1) l1 = qlo(n.lo1[k]), h1 = qhi(n.hi1[k]);
+            // the decoded box must contain the float box
+            if (!empty0 && !(rt_bvh_dequantize(frame, l0) <= double(n.lo0[k]) && rt_bvh_dequantize(frame, h0) >= double(n.hi0[k]))) return false;
+            if (!empty1 && !(rt_bvh_dequantize(frame, l1) <= double(n.lo1[k]) && rt_bvh_dequantize(frame, h1) >= double(n.hi1[k]))) return false;
+            q.frame[k] = frame;
+            q.q[k] = l0 | (h0 << 8) | (l1 << 16) | (h1 << 24);
+        }
+    }
+    return true;
+}

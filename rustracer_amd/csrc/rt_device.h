@@ -11,7 +11,7 @@
 //   materials [n_mat]     3 x float4, see DevMaterial
 //   texels    RGBA8, one u32 per texel, 8x8-texel tiles (64 consecutive u32 = 256 B per tile)
 //   tex_info  [n_tex]     {width, height, tiles_per_row, first_texel}
-//   bvh_nodes [n_nodes]   64 B each (both child boxes), bvh_recs [n_prims] 3 x float4 in leaf order, see DevBvhNode
+//   bvh_nodes [n_nodes]   32 B each (both child boxes, 8-bit quantised), bvh_recs [n_prims] 3 x float4 in leaf order, see DevBvhNodeQ
 #pragma once
 #include <stdint.h>
 
@@ -66,6 +66,21 @@ struct DevLight { float px, py, pz, _p0, ir, ig, ib, _p1; };
 #define RT_BVH_LEAF_BIT 0x80000000u
 #define RT_BVH_DONE 0x7fffffffu
 #define RT_BVH_MAX_PRIMS (1ull << 29)
+// The kernels read a 32-byte QUANTISED form of the node (DevBvhNodeQ): the traversal is bound by the number of vector-memory
+// instructions per node visit (a divergent 16-byte load occupies the CU's address unit for ~16-27 cycles whatever it hits),
+// and 32 bytes are two loads instead of four. Per axis k: frame[k] = the bits of a float origin o_k whose low 8 mantissa bits
+// are replaced by E_k, the biased exponent of a power-of-two step s_k = 2^(E_k - 127); q[k] = lo0 | hi0 << 8 | lo1 << 16 |
+// hi1 << 24, the bounds of the two children on that axis in steps from the origin: bound = o_k + q * s_k. The builder rounds
+// the origin down, lower bounds down and upper bounds up, so a quantised box always CONTAINS the float box (the traversal
+// visits a superset of nodes and returns the same hits). An empty child has lo = 255 > hi = 0.
+struct DevBvhNodeQ {
+    uint32_t frame[3];
+    uint32_t ref0;
+    uint32_t q[3];
+    uint32_t ref1;
+};
+
+// host-side form produced by the builder (float boxes), quantised by rt_bvh_quantize
 struct DevBvhNode {
     float lo0[3];
     uint32_t ref0;
@@ -101,7 +116,7 @@ struct KernelParams {
     const uint32_t *texels;
     const DevTexInfo *tex_info;
     const DevLight *lights;
-    const DevBvhNode *bvh_nodes;
+    const DevBvhNodeQ *bvh_nodes;
     const rt_f4 *bvh_recs;
     // outputs
     float *accum;        // context-owned running sum, owned_rows*width*3

@@ -142,25 +142,17 @@ __device__ __forceinline__ bool hit_tri(rt_f4 v0, rt_f4 e1_, rt_f4 e2_, const Ra
 // ---- BVH traversal (extension; big scenes) ----------------------------------------------------
 // "while-while" traversal (Aila & Laine 2009): every lane first walks inner nodes until it holds a
 // leaf (or is done), then the wave intersects leaves together, so that box tests and primitive
-// tests do not serialise against each other inside a wave. One 64-byte node fetch (4 independent
-// 16-byte loads) tests both children; the nearer child is entered first, the farther one is pushed
-// on the per-lane stack in LDS ([level][thread]: conflict-free).
+// tests do not serialise against each other inside a wave. One 32-byte node fetch (2 independent
+// 16-byte loads of 8-bit quantised boxes, DevBvhNodeQ) tests both children; the nearer child is entered first, the
+// farther one is pushed on the per-lane stack: its first P.bvh_levels levels in LDS ([level][thread]: conflict-free),
+// deeper ones in private memory.
 // A child is entered iff the ray's slab interval overlaps (tmin, min(best t, tmax)] — INCLUSIVE of
 // the current best t, so that an equal-t shape with a larger index is still found (ray.rs:55-61).
-// Slab planes are evaluated as fma(plane, 1/d, -o/d): against (plane - o)/d that moves a plane by
-// about one ulp of its coordinate, which the builder's box padding (rt_bvh.cpp) covers many times
-// over; a zero direction component gives NaN on that axis, which v_min/v_max drop (conservative).
+// Slab planes are evaluated as fma(q, step/d, fma(frame, 1/d, -o/d)) (q = the 8-bit plane index): against
+// (plane - o)/d that moves a plane by a few ulps of its coordinate, which the builder's box padding (rt_bvh.cpp)
+// covers many times over and the outward rounding of the quantiser only widens; a zero direction component gives
+// NaN on that axis, which v_min/v_max drop (conservative).
 #define RT_STACK_AT(level) s_stack[(level) * 256 + threadIdx.x]
-
-__device__ __forceinline__ bool slab_test(rt_f4 lo, rt_f4 hi, f3 inv_d, f3 noi, float tmin, float limit, float &tn_out) {
-    const float ax = fmaf(lo.x, inv_d.x, noi.x), bx = fmaf(hi.x, inv_d.x, noi.x);
-    const float ay = fmaf(lo.y, inv_d.y, noi.y), by = fmaf(hi.y, inv_d.y, noi.y);
-    const float az = fmaf(lo.z, inv_d.z, noi.z), bz = fmaf(hi.z, inv_d.z, noi.z);
-    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
-    tn_out = tn;
-    return tn <= tf && tn <= limit && tf >= tmin;
-}
 
 // Traversal state of one lane; it survives across calls of bvh_run so that a lane whose ray is
 // still inside the tree can be parked while the finished lanes of its wave shade and fetch new rays.
@@ -169,12 +161,17 @@ struct BvhState {
     uint32_t ref;   // node/leaf reference in flight, RT_BVH_DONE when the ray has left the tree
     int sp;
 };
+// stack levels >= P.bvh_levels of one lane (private memory; rarely reached, see rt_launch_render)
+struct BvhDeep { uint32_t at[RT_BVH_MAX_DEPTH]; };
 __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
     s.inv_d = mk3(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
     s.noi = mk3(-r.o.x * s.inv_d.x, -r.o.y * s.inv_d.y, -r.o.z * s.inv_d.z);
     s.ref = 0;  // the root is always an inner node
     s.sp = 0;
 }
+#ifndef RT_BVH_LDS_LEVELS
+#define RT_BVH_LDS_LEVELS 8u
+#endif
 #ifndef RT_BVH_LEAF_LANES
 #define RT_BVH_LEAF_LANES 16
 #endif
@@ -186,12 +183,50 @@ __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
 // give them new rays instead of idling them until the slowest ray of the wave is done (ray
 // lengths in the tree are heavy-tailed: without this a wave runs at ~20 % lane utilisation).
 // ANY: any-hit query, returns true on the first hit inside the window.
+// byte k of a dword as float (the compiler selects v_cvt_f32_ubyte0..3)
+__device__ __forceinline__ float ubyte0(uint32_t x) { return float(x & 0xffu); }
+__device__ __forceinline__ float ubyte1(uint32_t x) { return float((x >> 8) & 0xffu); }
+__device__ __forceinline__ float ubyte2(uint32_t x) { return float((x >> 16) & 0xffu); }
+__device__ __forceinline__ float ubyte3(uint32_t x) { return float(x >> 24); }
+
+// slab test from the six plane distances of a box (NaN = a zero direction component: dropped by v_min/v_max, conservative)
+__device__ __forceinline__ bool slab_from_t(float ax, float bx, float ay, float by, float az, float bz, float tmin, float limit, float &tn_out) {
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)) * 1.0000005f;
+    tn_out = tn;
+    return tn <= tf && tn <= limit && tf >= tmin;
+}
+
 template <bool STATS, bool ANY, bool YIELD>
-__device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uint32_t self, HitRec &h, BvhState &s, uint32_t *cnt, uint32_t *s_stack) {
-    const rt_f4 *nodes = (const rt_f4 *)P.bvh_nodes;
+__device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uint32_t self, HitRec &h, BvhState &s, BvhDeep &deep, uint32_t *cnt, uint32_t *s_stack) {
+    const uint4 *nodes = (const uint4 *)P.bvh_nodes;  // DevBvhNodeQ: 2 x 16 bytes
     uint32_t ref = s.ref;
     int sp = s.sp;
     bool found = false;
+    const int lds_levels = int(P.bvh_levels);
+    // (the asm statements keep the compiler from merging the LDS and the private access into one flat_ access)
+    auto push = [&](uint32_t x) {
+        if (sp < lds_levels) {
+            RT_STACK_AT(sp) = x;
+            asm volatile("" ::: "memory");
+        } else {
+            deep.at[sp - lds_levels] = x;
+            asm volatile("" ::: "memory");
+        }
+        sp++;
+    };
+    auto pop = [&]() -> uint32_t {
+        sp--;
+        uint32_t x;
+        if (sp < lds_levels) {
+            x = RT_STACK_AT(sp);
+            asm volatile("" : "+v"(x));
+        } else {
+            x = deep.at[sp - lds_levels];
+            asm volatile("" : "+v"(x));
+        }
+        return x;
+    };
     for (;;) {
         // inner nodes: every lane walks down until RT_BVH_LEAF_LANES lanes of the wave wait at a leaf (waiting for
         // the LAST lane to reach one leaves three quarters of the wave idle: the walk lengths are heavy-tailed)
@@ -204,23 +239,29 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
           }
 #endif
           if (ref < RT_BVH_DONE) {
-            const rt_f4 q0 = nodes[4 * ref], q1 = nodes[4 * ref + 1], q2 = nodes[4 * ref + 2], q3 = nodes[4 * ref + 3];
+            const uint4 na = nodes[2 * ref], nb = nodes[2 * ref + 1];  // {frame x, y, z, ref0} {q x, y, z, ref1}
             if (STATS) cnt[RT_STAT_NODE] += 2;
             const float limit = ANY ? r.tmax : fminf(h.t, r.tmax);
+            // per axis: plane distance t = (o + q*step)/d - origin/d = q * (step/d) + (o/d - origin/d)
+            const float Ax = __uint_as_float((na.x & 0xffu) << 23) * s.inv_d.x, Bx = fmaf(__uint_as_float(na.x & 0xffffff00u), s.inv_d.x, s.noi.x);
+            const float Ay = __uint_as_float((na.y & 0xffu) << 23) * s.inv_d.y, By = fmaf(__uint_as_float(na.y & 0xffffff00u), s.inv_d.y, s.noi.y);
+            const float Az = __uint_as_float((na.z & 0xffu) << 23) * s.inv_d.z, Bz = fmaf(__uint_as_float(na.z & 0xffffff00u), s.inv_d.z, s.noi.z);
             float tn0, tn1;
-            const bool h0 = slab_test(q0, q1, s.inv_d, s.noi, r.tmin, limit, tn0);
-            const bool h1 = slab_test(q2, q3, s.inv_d, s.noi, r.tmin, limit, tn1);
-            const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
+            const bool h0 = slab_from_t(fmaf(ubyte0(nb.x), Ax, Bx), fmaf(ubyte1(nb.x), Ax, Bx),
+                                        fmaf(ubyte0(nb.y), Ay, By), fmaf(ubyte1(nb.y), Ay, By),
+                                        fmaf(ubyte0(nb.z), Az, Bz), fmaf(ubyte1(nb.z), Az, Bz), r.tmin, limit, tn0);
+            const bool h1 = slab_from_t(fmaf(ubyte2(nb.x), Ax, Bx), fmaf(ubyte3(nb.x), Ax, Bx),
+                                        fmaf(ubyte2(nb.y), Ay, By), fmaf(ubyte3(nb.y), Ay, By),
+                                        fmaf(ubyte2(nb.z), Az, Bz), fmaf(ubyte3(nb.z), Az, Bz), r.tmin, limit, tn1);
+            const uint32_t r0 = na.w, r1 = nb.w;
             if (h0 & h1) {
                 const bool second_first = tn1 < tn0;
-                RT_STACK_AT(sp) = second_first ? r0 : r1;
-                sp++;
+                push(second_first ? r0 : r1);
                 ref = second_first ? r1 : r0;
             } else if (h0 | h1) {
                 ref = h0 ? r0 : r1;
             } else if (sp > 0) {
-                sp--;
-                ref = RT_STACK_AT(sp);
+                ref = pop();
             } else {
                 ref = RT_BVH_DONE;
             }
@@ -261,8 +302,7 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
                 }
             }
             if (sp > 0 && !(ANY && found)) {
-                sp--;
-                ref = RT_STACK_AT(sp);
+                ref = pop();
             } else {
                 ref = RT_BVH_DONE;
             }
@@ -359,8 +399,9 @@ __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &
         }
     } else {
         BvhState bs;
+        BvhDeep deep;
         bvh_begin(r, bs);
-        bvh_run<STATS, false, false>(P, r, self, h, bs, cnt, s_stack);
+        bvh_run<STATS, false, false>(P, r, self, h, bs, deep, cnt, s_stack);
     }
     if (STATS) cnt[RT_STAT_PLANE] += P.n_planes;
     return h;
@@ -391,8 +432,9 @@ __device__ __forceinline__ bool occluded(const KernelParams &P, const Ray &r, ui
         dummy.t = r.tmax;
         dummy.shape = RT_NONE;
         BvhState bs;
+        BvhDeep deep;
         bvh_begin(r, bs);
-        occ = bvh_run<STATS, true, false>(P, r, self, dummy, bs, cnt, s_stack);
+        occ = bvh_run<STATS, true, false>(P, r, self, dummy, bs, deep, cnt, s_stack);
     }
     return occ;
 }
@@ -481,8 +523,14 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 // Dynamic LDS layout (bytes): [MODE_LDS: RT_LDS_SPHERES x 16 geometry | 3 x n_spheres x 16 shading]
 // [MODE_BVH: bvh_levels x 256 x 4 traversal stack | 4 waves x 64 x 8 per-pixel {RNG key, x | y << 16}
 // | 4 waves x 3 x 64*chunk x 4 radiance slots]; rt_launch_render computes the size.
+// MODE_BVH is latency-bound (every node visit is a dependent 32-byte fetch that mostly hits L2): its speed follows the number
+// of resident waves (measured on C4/C5: 4 -> 5 -> 6 -> 7 waves per SIMD = 1.00 / 1.11 / 1.18 / 1.21), so the kernel is held to
+// 72 VGPRs (20 dwords of spills, outside the traversal loop) and its LDS to 22 KB per workgroup (see rt_launch_render).
+#ifndef RT_BVH_WAVES
+#define RT_BVH_WAVES 7
+#endif
 template <bool STATS, int MODE, bool LIGHTS>
-__global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 5) : (MODE == MODE_BVH ? 5 : 7))) void render_kernel(const KernelParams P) {
+__global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 5) : (MODE == MODE_BVH ? RT_BVH_WAVES : 7))) void render_kernel(const KernelParams P) {
     constexpr bool POOL = MODE == MODE_BVH;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     rt_f4 *s_geom_mem = (rt_f4 *)s_dyn;
@@ -578,6 +626,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 
         HitRec h;
         h.t = 0.0f, h.shape = RT_NONE, h.b1 = h.b2 = 0.0f;
         BvhState bs;           // MODE_BVH: the closest-hit query is resumable
+        BvhDeep deep;
         bs.ref = RT_BVH_DONE, bs.sp = 0, bs.inv_d = bs.noi = mk3(0.0f, 0.0f, 0.0f);
         bool tracing = false;  // ... and this lane's ray is still inside the tree
         // what shade() leaves behind for next_ray(): the hit point, the surface and the mirror direction
@@ -621,7 +670,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 
                     }
                 }
                 if (tracing) {
-                    bvh_run<STATS, false, true>(P, r, self, h, bs, cnt, s_stack);
+                    bvh_run<STATS, false, true>(P, r, self, h, bs, deep, cnt, s_stack);
                     if (bs.ref != RT_BVH_DONE) return 2;  // parked: the finished lanes of the wave shade and fetch new work
                     tracing = false;
                 }
@@ -1125,6 +1174,11 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
         if (P.bvh_levels == 0 || P.bvh_levels > RT_BVH_MAX_DEPTH) return hipErrorInvalidValue;
         P.chunk = default_chunk();
         if (P.chunk > P.spp) P.chunk = P.spp;
+        // only the first levels of the traversal stack live in LDS, deeper ones in private memory (a lane is that deep on
+        // a few per cent of its pushes): 8 KB + 2 KB + 12 KB lets 7 workgroups share a CU's 160 KB
+        uint32_t lds_levels = RT_BVH_LDS_LEVELS;
+        if (const char *e = getenv("RTHIP_STACK_LDS")) lds_levels = uint32_t(atoi(e));  // tuning knob; results do not depend on it
+        if (lds_levels < P.bvh_levels) P.bvh_levels = lds_levels;
         lds = P.bvh_levels * 1024u + 2048u + 4u * 3u * 64u * 4u * P.chunk;
     } else {
         P.chunk = P.spp;  // lane = pixel: one "chunk", no radiance slots

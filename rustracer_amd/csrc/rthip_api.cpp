@@ -401,7 +401,9 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
         uint32_t bvh_levels = 0;
         if (s->n_spheres + s->n_triangles > RT_BVH_THRESHOLD) bvh_levels = rt_build_bvh(s, nodes, prims);
         if (bvh_levels > RT_BVH_MAX_DEPTH) return fail(ctx, RTHIP_E_INTERNAL, "BVH deeper than the traversal stack");
-        if ((st = upload(ctx, ctx->bvh_nodes, nodes.data(), nodes.size() * sizeof(DevBvhNode)))) return st;
+        std::vector<DevBvhNodeQ> qnodes;
+        if (!rt_bvh_quantize(nodes, qnodes)) return fail(ctx, RTHIP_E_INTERNAL, "BVH node quantisation failed");
+        if ((st = upload(ctx, ctx->bvh_nodes, qnodes.data(), qnodes.size() * sizeof(DevBvhNodeQ)))) return st;
         // primitives in leaf order, self-contained records (geometry + global shape index + kind)
         std::vector<rt_f4> recs(3 * prims.size());
         for (size_t j = 0; j < prims.size(); j++) {
@@ -429,7 +431,7 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
         k.materials = (const DevMaterial *)ctx->materials.p;
         k.texels = (const uint32_t *)ctx->texels.p, k.tex_info = (const DevTexInfo *)ctx->tex_info.p;
         k.lights = (const DevLight *)ctx->lights.p;
-        k.bvh_nodes = (const DevBvhNode *)ctx->bvh_nodes.p, k.bvh_recs = (const rt_f4 *)ctx->bvh_recs.p;
+        k.bvh_nodes = (const DevBvhNodeQ *)ctx->bvh_nodes.p, k.bvh_recs = (const rt_f4 *)ctx->bvh_recs.p;
         ctx->n_shapes = n_shapes;
         ctx->have_scene = true;
         ctx->nb_samples = 0;  // a new scene invalidates the running sum

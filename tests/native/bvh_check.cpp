@@ -128,6 +128,27 @@ int main(int argc, char **argv) {
     }
     if (c.max_levels != levels) return fail("reported stack levels != tree depth", levels, c.max_levels);
     if (levels > RT_BVH_MAX_DEPTH) return fail("deeper than the traversal stack", levels);
+    // the 32-byte quantised nodes the kernels read: same references, every decoded box contains the float box, empty stays empty
+    std::vector<DevBvhNodeQ> qn;
+    if (!rt_bvh_quantize(nodes, qn) || qn.size() != nodes.size()) return fail("quantisation failed");
+    for (size_t i = 0; i < nodes.size(); i++) {
+        const DevBvhNode &n = nodes[i];
+        if (qn[i].ref0 != n.ref0 || qn[i].ref1 != n.ref1) return fail("quantised references differ", long(i));
+        const bool empty1 = n.lo1[0] > n.hi1[0];
+        for (int k = 0; k < 3; k++) {
+            const uint32_t f = qn[i].frame[k], q = qn[i].q[k];
+            if ((f & 0xffu) == 0u || (f & 0xffu) == 0xffu) return fail("step exponent not a normal float", long(i), k);
+            if (!(rt_bvh_dequantize(f, q & 0xff) <= double(n.lo0[k]) && rt_bvh_dequantize(f, (q >> 8) & 0xff) >= double(n.hi0[k])))
+                return fail("quantised box 0 does not contain the float box", long(i), k);
+            if (empty1 ? !(((q >> 16) & 0xff) == 255 && (q >> 24) == 0)
+                       : !(rt_bvh_dequantize(f, (q >> 16) & 0xff) <= double(n.lo1[k]) && rt_bvh_dequantize(f, q >> 24) >= double(n.hi1[k])))
+                return fail("quantised box 1 wrong", long(i), k);
+            // not looser than two steps beyond the float box
+            const double step = rt_bvh_dequantize(f, 1) - rt_bvh_dequantize(f, 0);
+            if (double(n.lo0[k]) - rt_bvh_dequantize(f, q & 0xff) > step || rt_bvh_dequantize(f, (q >> 8) & 0xff) - double(n.hi0[k]) > step)
+                return fail("quantised box 0 looser than one step", long(i), k);
+        }
+    }
     // FNV-1a over the node and primitive arrays: the threaded build must give the tree of the serial one
     uint64_t hsh = 1469598103934665603ull;
     auto mix = [&](const void *p, size_t bytes) {

@@ -238,6 +238,29 @@ def test_bvh_equals_brute_force(oracle_mod, default_camera):
     rt.close()
 
 
+def test_bvh_stack_split_does_not_change_the_image(monkeypatch):
+    # the traversal stack keeps its first levels in LDS and deeper ones in private memory; where the split lies is a
+    # tuning knob (RTHIP_STACK_LDS) and must not show: 1 level in LDS (nearly every push goes to private memory),
+    # the default (8) and all levels in LDS give the same bits, with and without point lights, and all equal the linear scan
+    from rustracer_amd import PointLight
+    flat = flatten(presets.big_scene(n_side=24, seed=9, mesh_subdivisions=3),  # 577 spheres + 1280 triangles: tree deeper than 8
+                   [PointLight((4.0, 5.0, 2.0), (30.0, 30.0, 30.0))])
+    rt = Raytracer.new(256, 144, seed=5)
+    for flags in (0, abi.F_POINT_LIGHTS):
+        brute = rt.render(flat, 3, max_depth=6, flags=flags | abi.F_NO_BVH)
+        images = []
+        for levels in ("1", "3", None, "32"):
+            if levels is None:
+                monkeypatch.delenv("RTHIP_STACK_LDS", raising=False)
+            else:
+                monkeypatch.setenv("RTHIP_STACK_LDS", levels)
+            r = rt.render(flat, 3, max_depth=6, flags=flags | abi.F_COUNT_STATS)
+            images.append(r)
+            assert np.array_equal(r.accum, brute.accum) and np.array_equal(r.rgba8, brute.rgba8), levels
+        assert len({r.stats["node_tests"] for r in images}) == 1
+    rt.close()
+
+
 def test_bvh_tie_break_duplicates():
     # 200 coincident sphere pairs: equal t everywhere; the larger index must win inside the BVH too
     rng = np.random.default_rng(2)
