@@ -232,18 +232,21 @@ uint32_t rt_build_bvh(const rthip_scene_desc *s, std::vector<DevBvhNode> &nodes,
 namespace {
 inline uint32_t f_bits(float x) { uint32_t u; std::memcpy(&u, &x, 4); return u; }
 inline float bits_f(uint32_t u) { float x; std::memcpy(&x, &u, 4); return x; }
-// the largest float <= x whose low 8 mantissa bits are zero
-inline float round_down_frame(float x) {
+// Frame origin of an axis: a float <= x whatever the low 8 bits of its pattern are set to afterwards (they carry the step
+// exponent and the kernel does NOT mask them off: the origin is the float with those bits in it).
+inline uint32_t frame_base(float x) {
     uint32_t u = f_bits(x);
-    if (!(u & 0x80000000u)) return bits_f(u & 0xffffff00u);   // positive: towards zero is down
-    if (u & 0xffu) u = (u | 0xffu) + 1u;                       // negative: away from zero
-    return bits_f(u);
+    if (!(u & 0x80000000u)) {
+        u &= 0xffffff00u;
+        return u >= 0x100u ? u - 0x100u : 0x80000100u;  // one frame step down; below +0: a tiny negative base
+    }
+    return (u | 0xffu) + 1u;  // negative: away from zero, low bits zero again (adding the exponent byte moves it further down)
 }
 }  // namespace
 
 double rt_bvh_dequantize(uint32_t frame, uint32_t q8) {
-    const double origin = double(bits_f(frame & 0xffffff00u));
-    const double step = std::ldexp(1.0, int(frame & 0xffu) - 127);
+    const double origin = double(bits_f(frame));
+    const double step = std::ldexp(1.0, int(int8_t(frame & 0xffu)));
     return origin + double(q8) * step;
 }
 
@@ -259,21 +262,24 @@ bool rt_bvh_quantize(const std::vector<DevBvhNode> &nodes, std::vector<DevBvhNod
             if (!empty0) lo = std::min(lo, n.lo0[k]), hi = std::max(hi, n.hi0[k]);
             if (!empty1) lo = std::min(lo, n.lo1[k]), hi = std::max(hi, n.hi1[k]);
             if (!(lo <= hi) || !std::isfinite(lo) || !std::isfinite(hi)) return false;
-            const float origin = round_down_frame(lo);
-            if (!std::isfinite(origin) || origin > lo) return false;
-            const double extent = double(hi) - double(origin);
-            int e = 1;  // biased exponent of the step; >= 1 keeps the step a normal float
+            const uint32_t base = frame_base(lo);
+            // the lowest value the origin can take once the exponent byte is in: positive patterns grow with it, negative ones fall
+            const float lowest = bits_f((base & 0x80000000u) ? (base | 0xffu) : base);
+            if (!std::isfinite(lowest) || lowest > lo) return false;
+            const double extent = double(hi) - double(lowest);
+            int e = -126;  // step = 2^e, a normal float; e travels as a signed byte
             if (extent > 0.0) {
                 int ex;
-                std::frexp(extent / 255.0, &ex);   // extent / 255 = m * 2^ex, m in [0.5, 1)  =>  2^ex >= extent / 255
-                e = std::max(1, ex + 127);
+                std::frexp(extent / 255.0, &ex);  // extent / 255 = m * 2^ex, m in [0.5, 1)  =>  2^ex >= extent / 255
+                e = std::max(-126, ex);
             }
-            while (e < 254 && 255.0 * std::ldexp(1.0, e - 127) < extent) e++;
-            if (255.0 * std::ldexp(1.0, e - 127) < extent) return false;
-            const double step = std::ldexp(1.0, e - 127);
-            const uint32_t frame = (f_bits(origin) & 0xffffff00u) | uint32_t(e);
-            auto qlo = [&](float v) { double t = std::floor((double(v) - double(origin)) / step); return uint32_t(std::min(255.0, std::max(0.0, t))); };
-            auto qhi = [&](float v) { double t = std::ceil((double(v) - double(origin)) / step); return uint32_t(std::min(255.0, std::max(0.0, t))); };
+            while (e < 127 && 255.0 * std::ldexp(1.0, e) < extent) e++;
+            if (255.0 * std::ldexp(1.0, e) < extent) return false;
+            const uint32_t frame = base | (uint32_t(e) & 0xffu);
+            const double origin = double(bits_f(frame)), step = std::ldexp(1.0, e);
+            if (!(origin <= double(lo))) return false;
+            auto qlo = [&](float v) { double t = std::floor((double(v) - origin) / step); return uint32_t(std::min(255.0, std::max(0.0, t))); };
+            auto qhi = [&](float v) { double t = std::ceil((double(v) - origin) / step); return uint32_t(std::min(255.0, std::max(0.0, t))); };
             uint32_t l0 = 255, h0 = 0, l1 = 255, h1 = 0;
             if (!empty0) l0 = qlo(n.lo0[k]), h0 = qhi(n.hi0[k]);
             if (!empty1) l1 = qlo(n.lo1[k]), h1 = qhi(n.hi1[k]);

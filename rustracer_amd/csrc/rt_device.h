@@ -68,11 +68,11 @@ struct DevLight { float px, py, pz, _p0, ir, ig, ib, _p1; };
 #define RT_BVH_MAX_PRIMS (1ull << 29)
 // The kernels read a 32-byte QUANTISED form of the node (DevBvhNodeQ): the traversal is bound by the number of vector-memory
 // instructions per node visit (a divergent 16-byte load occupies the CU's address unit for ~16-27 cycles whatever it hits),
-// and 32 bytes are two loads instead of four. Per axis k: frame[k] = the bits of a float origin o_k whose low 8 mantissa bits
-// are replaced by E_k, the biased exponent of a power-of-two step s_k = 2^(E_k - 127); q[k] = lo0 | hi0 << 8 | lo1 << 16 |
-// hi1 << 24, the bounds of the two children on that axis in steps from the origin: bound = o_k + q * s_k. The builder rounds
-// the origin down, lower bounds down and upper bounds up, so a quantised box always CONTAINS the float box (the traversal
-// visits a superset of nodes and returns the same hits). An empty child has lo = 255 > hi = 0.
+// and 32 bytes are two loads instead of four. Per axis k: frame[k] is the bit pattern of the float origin o_k, whose low 8
+// bits double as e_k, the (signed) exponent of the power-of-two step s_k = 2^e_k; q[k] = lo0 | hi0 << 8 | lo1 << 16 |
+// hi1 << 24, the bounds of the two children on that axis in steps from the origin: bound = o_k + q * s_k. The builder puts
+// the origin below the boxes and rounds lower bounds down and upper bounds up, so a quantised box always CONTAINS the float
+// box (the traversal visits a superset of nodes and returns the same hits). An empty child has lo = 255 > hi = 0.
 struct DevBvhNodeQ {
     uint32_t frame[3];
     uint32_t ref0;

@@ -158,6 +158,7 @@ __device__ __forceinline__ bool hit_tri(rt_f4 v0, rt_f4 e1_, rt_f4 e2_, const Ra
 // still inside the tree can be parked while the finished lanes of its wave shade and fetch new rays.
 struct BvhState {
     f3 inv_d, noi;  // 1/d and -o/d
+    uint32_t selx, sely, selz;  // v_perm selectors that put the near plane of each child first (by the sign of d)
     uint32_t ref;   // node/leaf reference in flight, RT_BVH_DONE when the ray has left the tree
     int sp;
 };
@@ -166,6 +167,9 @@ struct BvhDeep { uint32_t at[RT_BVH_MAX_DEPTH]; };
 __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
     s.inv_d = mk3(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
     s.noi = mk3(-r.o.x * s.inv_d.x, -r.o.y * s.inv_d.y, -r.o.z * s.inv_d.z);
+    s.selx = s.inv_d.x < 0.0f ? 0x02030001u : 0x03020100u;
+    s.sely = s.inv_d.y < 0.0f ? 0x02030001u : 0x03020100u;
+    s.selz = s.inv_d.z < 0.0f ? 0x02030001u : 0x03020100u;
     s.ref = 0;  // the root is always an inner node
     s.sp = 0;
 }
@@ -243,22 +247,24 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
             if (STATS) cnt[RT_STAT_NODE] += 2;
             const float limit = ANY ? r.tmax : fminf(h.t, r.tmax);
             // per axis: plane distance t = (o + q*step)/d - origin/d = q * (step/d) + (o/d - origin/d)
-            const float Ax = __uint_as_float((na.x & 0xffu) << 23) * s.inv_d.x, Bx = fmaf(__uint_as_float(na.x & 0xffffff00u), s.inv_d.x, s.noi.x);
-            const float Ay = __uint_as_float((na.y & 0xffu) << 23) * s.inv_d.y, By = fmaf(__uint_as_float(na.y & 0xffffff00u), s.inv_d.y, s.noi.y);
-            const float Az = __uint_as_float((na.z & 0xffu) << 23) * s.inv_d.z, Bz = fmaf(__uint_as_float(na.z & 0xffffff00u), s.inv_d.z, s.noi.z);
-            float tn0, tn1;
-            const bool h0 = slab_from_t(fmaf(ubyte0(nb.x), Ax, Bx), fmaf(ubyte1(nb.x), Ax, Bx),
-                                        fmaf(ubyte0(nb.y), Ay, By), fmaf(ubyte1(nb.y), Ay, By),
-                                        fmaf(ubyte0(nb.z), Az, Bz), fmaf(ubyte1(nb.z), Az, Bz), r.tmin, limit, tn0);
-            const bool h1 = slab_from_t(fmaf(ubyte2(nb.x), Ax, Bx), fmaf(ubyte3(nb.x), Ax, Bx),
-                                        fmaf(ubyte2(nb.y), Ay, By), fmaf(ubyte3(nb.y), Ay, By),
-                                        fmaf(ubyte2(nb.z), Az, Bz), fmaf(ubyte3(nb.z), Az, Bz), r.tmin, limit, tn1);
+            const float Ax = ldexpf(s.inv_d.x, __builtin_amdgcn_sbfe(int(na.x), 0, 8)), Bx = fmaf(__uint_as_float(na.x), s.inv_d.x, s.noi.x);
+            const float Ay = ldexpf(s.inv_d.y, __builtin_amdgcn_sbfe(int(na.y), 0, 8)), By = fmaf(__uint_as_float(na.y), s.inv_d.y, s.noi.y);
+            const float Az = ldexpf(s.inv_d.z, __builtin_amdgcn_sbfe(int(na.z), 0, 8)), Bz = fmaf(__uint_as_float(na.z), s.inv_d.z, s.noi.z);
+            // bytes {near0, far0, near1, far1} per axis: with the planes picked by the sign of d, a child's entry distance is
+            // the max of three, its exit the min of three (NaN = zero direction component on that axis: dropped)
+            const uint32_t px = __builtin_amdgcn_perm(nb.x, nb.x, s.selx), py = __builtin_amdgcn_perm(nb.y, nb.y, s.sely), pz = __builtin_amdgcn_perm(nb.z, nb.z, s.selz);
+            const float tn0 = fmaxf(fmaxf(fmaf(ubyte0(px), Ax, Bx), fmaf(ubyte0(py), Ay, By)), fmaf(ubyte0(pz), Az, Bz));
+            const float tf0 = fminf(fminf(fmaf(ubyte1(px), Ax, Bx), fmaf(ubyte1(py), Ay, By)), fmaf(ubyte1(pz), Az, Bz)) * 1.0000005f;
+            const float tn1 = fmaxf(fmaxf(fmaf(ubyte2(px), Ax, Bx), fmaf(ubyte2(py), Ay, By)), fmaf(ubyte2(pz), Az, Bz));
+            const float tf1 = fminf(fminf(fmaf(ubyte3(px), Ax, Bx), fmaf(ubyte3(py), Ay, By)), fmaf(ubyte3(pz), Az, Bz)) * 1.0000005f;
+            const bool h0 = tn0 <= tf0 && tn0 <= limit && tf0 >= r.tmin;
+            const bool h1 = tn1 <= tf1 && tn1 <= limit && tf1 >= r.tmin;
             const uint32_t r0 = na.w, r1 = nb.w;
-            if (h0 & h1) {
+            if (h0 && h1) {
                 const bool second_first = tn1 < tn0;
                 push(second_first ? r0 : r1);
                 ref = second_first ? r1 : r0;
-            } else if (h0 | h1) {
+            } else if (h0 || h1) {
                 ref = h0 ? r0 : r1;
             } else if (sp > 0) {
                 ref = pop();
@@ -526,11 +532,14 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 // MODE_BVH is latency-bound (every node visit is a dependent 32-byte fetch that mostly hits L2): its speed follows the number
 // of resident waves (measured on C4/C5: 4 -> 5 -> 6 -> 7 waves per SIMD = 1.00 / 1.11 / 1.18 / 1.21), so the kernel is held to
 // 72 VGPRs (20 dwords of spills, outside the traversal loop) and its LDS to 22 KB per workgroup (see rt_launch_render).
+#ifndef RT_BVH_LIGHT_WAVES
+#define RT_BVH_LIGHT_WAVES 5
+#endif
 #ifndef RT_BVH_WAVES
 #define RT_BVH_WAVES 7
 #endif
 template <bool STATS, int MODE, bool LIGHTS>
-__global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? 4 : 5) : (MODE == MODE_BVH ? RT_BVH_WAVES : 7))) void render_kernel(const KernelParams P) {
+__global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_BVH_LIGHT_WAVES : 5) : (MODE == MODE_BVH ? RT_BVH_WAVES : 7))) void render_kernel(const KernelParams P) {
     constexpr bool POOL = MODE == MODE_BVH;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     rt_f4 *s_geom_mem = (rt_f4 *)s_dyn;

@@ -137,7 +137,7 @@ int main(int argc, char **argv) {
         const bool empty1 = n.lo1[0] > n.hi1[0];
         for (int k = 0; k < 3; k++) {
             const uint32_t f = qn[i].frame[k], q = qn[i].q[k];
-            if ((f & 0xffu) == 0u || (f & 0xffu) == 0xffu) return fail("step exponent not a normal float", long(i), k);
+            if (int(int8_t(f & 0xffu)) < -126) return fail("step exponent not a normal float", long(i), k);
             if (!(rt_bvh_dequantize(f, q & 0xff) <= double(n.lo0[k]) && rt_bvh_dequantize(f, (q >> 8) & 0xff) >= double(n.hi0[k])))
                 return fail("quantised box 0 does not contain the float box", long(i), k);
             if (empty1 ? !(((q >> 16) & 0xff) == 255 && (q >> 24) == 0)

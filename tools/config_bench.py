@@ -1,5 +1,5 @@
 """Timing of the SURVEY §8d configurations C2-C5 on one GPU (instrumented + plain runs).
-usage: python tools/config_bench.py [C2 C2d50 C2L C3 C4 C5] ; env SPP_SCALE=0.25 scales the sample counts;
+usage: python tools/config_bench.py [C2 C2d50 C2L C3 C4 C4L C5] ; env SPP_SCALE=0.25 scales the sample counts;
 CPU_CROP=64 also times the CPU oracle (f64, all host threads, brute force: it has no BVH) on a CPU_CROP^2 window in the
 middle of the frame at 1 spp (the CPU baseline of C4/C5 is a cropped window, reported in Mrays/s)."""
 import json, os, sys, time
@@ -15,6 +15,7 @@ CONFIGS = {
     "C2L": dict(scene=presets.standalone_scene, lights=presets.standalone_lights, flags=abi.F_POINT_LIGHTS, w=3840, h=2160, spp=256, depth=5),
     "C3": dict(scene=presets.textured_scene, w=3840, h=2160, spp=64, depth=50),
     "C4": dict(scene=presets.mesh_scene, w=3840, h=2160, spp=16, depth=50),
+    "C4L": dict(scene=presets.mesh_scene, lights=presets.standalone_lights, flags=abi.F_POINT_LIGHTS, w=3840, h=2160, spp=16, depth=50),
     "C5": dict(scene=lambda: presets.big_scene(100, 7, 6), w=7680, h=4320, spp=64, depth=8),
 }
 names = sys.argv[1:] or ["C2", "C3", "C4", "C5"]
