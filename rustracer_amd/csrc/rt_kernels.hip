@@ -518,17 +518,18 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 //    sample at once (path regeneration), so lanes only idle at the very end of a tile.
 //  * MODE_BVH (POOL): per-ray cost in a tree is heavy-tailed and differs a lot between the pixels of a
 //    tile (sky vs. mesh silhouette): with lane = pixel 80 % of the lanes idle. So a lane does NOT own
-//    a pixel while tracing: the tile's (pixel, sample) pairs of a chunk of `P.chunk` samples form a
-//    pool of 64*chunk work items, item i = (pixel i & 63, sample i >> 6), and a lane whose path has
-//    ended takes the next item of the pool (ballot + prefix count, no atomics). Each finished item
-//    stores its radiance in its own LDS slot; at the end of a chunk lane p adds the slots of pixel p
-//    in sample order, so the sum is exactly that of the sequential loop of lib.rs:281-288 and
+//    a pixel while tracing: the tile's (pixel, sample) pairs are work items, item i = (pixel i & 63,
+//    sample i >> 6), and a lane whose path has ended takes the next item (ballot + prefix count, no
+//    atomics). Each finished item stores its radiance in its own LDS slot, in a ring of `P.chunk`
+//    sample rows; when the last path of the oldest row has ended lane p adds that row's slot of pixel p
+//    to its sum, so the samples are added in sample order exactly like the sequential loop of
+//    lib.rs:281-288,
 //    independent of which lane traced what. (Measured: the pool costs the scan modes 9 % — their
 //    idle lanes come from divergent shading branches, not from unequal pixels — hence not used there.)
 //
 // Dynamic LDS layout (bytes): [MODE_LDS: RT_LDS_SPHERES x 16 geometry | 3 x n_spheres x 16 shading]
 // [MODE_BVH: bvh_levels x 256 x 4 traversal stack | 4 waves x 64 x 8 per-pixel {RNG key, x | y << 16}
-// | 4 waves x 3 x 64*chunk x 4 radiance slots]; rt_launch_render computes the size.
+// | 4 waves x 3 x 64*chunk x 4 radiance slots | 4 waves x 16 x 4 finished paths per ring row]; rt_launch_render computes the size.
 // MODE_BVH is latency-bound (every node visit is a dependent 32-byte fetch that mostly hits L2): its speed follows the number
 // of resident waves (measured on C4/C5: 4 -> 5 -> 6 -> 7 waves per SIMD = 1.00 / 1.11 / 1.18 / 1.21), so the kernel is held to
 // 72 VGPRs (20 dwords of spills, outside the traversal loop) and its LDS to 22 KB per workgroup (see rt_launch_render).
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
         uint2 *s_pix = s_pix_all + (wave << 6);
         const uint32_t plane = P.chunk << 6;  // floats per colour plane of the wave's radiance slots
         float *s_L = s_L_all + wave * 3u * plane;
+        uint32_t *s_rows = (uint32_t *)(s_L_all + 4u * 3u * plane) + (wave << 4);  // MODE_BVH: per ring slot, the paths that have ended
         rt_f4 pp_own;
         {
             // per pixel: direction through its lower-left corner d00 + H*x/(W-1) + V*y/(H-1) (camera.rs:46-48,
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
         const f3 cam_o = mk3(P.ox, P.oy, P.oz);
         f3 acc = mk3(0.0f, 0.0f, 0.0f);
         // ---- state of the path this lane is tracing ----
-        uint32_t item = 0;   // slot of the work item in the chunk
+        uint32_t item = 0;   // radiance slot of the work item: ring row << 6 | pixel
         uint32_t key = 0;    // RNG counter of the slot in use (advances by GOLDEN per segment)
         uint32_t bounce = 0;
         uint32_t self = RT_NONE;  // shape the current ray starts on
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
         auto emit = [&](f3 L) {
             if (LIGHTS) L = L + Ld;
             if constexpr (POOL) {
-                s_L[item] = L.x;  // lib.rs:287, summed in sample order at the end of the chunk
+                s_L[item] = L.x;  // lib.rs:287, summed in sample order when the row is retired
                 s_L[plane + item] = L.y;
                 s_L[2u * plane + item] = L.z;
             } else {
@@ -958,49 +960,59 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 cnt[RT_STAT_PATHS] += s_done;
             }
         } else {
-            for (uint32_t s_base = 0; s_base < n_spp; s_base += P.chunk) {
-                const uint32_t total = min(P.chunk, n_spp - s_base) << 6;  // work items of this chunk
-                uint32_t next = 0;                                          // first item not yet handed out (wave-uniform)
-                bool have = false;                                          // this lane is tracing a path
-                for (;;) {
-                    // ---- idle lanes take the next items of the pool, in lane order ----
-                    const unsigned long long need = __ballot(!have);
-                    if (!have) {
-                        const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi(uint32_t(need >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(need), 0u));
-                        if (idx < total && ((amask >> (idx & 63u)) & 1ull)) {
-                            item = idx;
-                            have = true;
-                            next_ray(true, idx & 63u, P.sample0 + s_first + s_base + (idx >> 6));
-                        }
-                    }
-                    next = min(next + uint32_t(__popcll(need)), total);
-                    if (__ballot(have) == 0ull) break;
-                    if (have) {
-                        const int st = shade();
-                        if (st == 1) {
-                            cnt[RT_STAT_PATHS]++;
-                            have = false;
-                        } else if (st == 0) {
-                            next_ray(false, 0, 0);
-                        }
-                    }
-                }
-                // ---- lane p adds the samples of pixel p, in sample order ----
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (active) {
-                    for (uint32_t k = lane; k < total; k += 64u) {
+            // Work items in hand-out order: item i = (pixel i & 63, sample i >> 6). The radiance of sample row r waits in ring
+            // slot r & (rows - 1); the oldest row is retired (added to the pixels' sums, in sample order) as soon as its last
+            // path has ended, and items are handed out up to `rows` rows ahead of it — the wave idles lanes for the slowest
+            // paths only at the very end of its samples, not once per chunk.
+            const uint32_t rows = P.chunk, total = n_spp << 6, expect = uint32_t(__popcll(amask));
+            if (lane < 16u) s_rows[lane] = 0u;  // paths that have ended, per ring slot
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t next = 0;      // first item not yet handed out (wave-uniform)
+            uint32_t oldest = 0;    // first sample row not yet retired (wave-uniform)
+            bool have = false;      // this lane is tracing a path
+            for (;;) {
+                // ---- retire the rows whose paths have all ended ----
+                while (oldest < n_spp && uint32_t(__builtin_amdgcn_readfirstlane(int(s_rows[oldest & (rows - 1u)]))) == expect) {
+                    const uint32_t k = ((oldest & (rows - 1u)) << 6) + lane;
+                    if (active) {
                         grp.x += s_L[k];
                         grp.y += s_L[plane + k];
                         grp.z += s_L[2u * plane + k];
                     }
-                    if ((s_base + P.chunk) % P.slice_spp == 0u || s_base + P.chunk >= n_spp) {
+                    if (lane == 0u) s_rows[oldest & (rows - 1u)] = 0u;
+                    oldest++;
+                    if (oldest % P.slice_spp == 0u || oldest == n_spp) {
                         acc = acc + grp;
                         grp = mk3(0.0f, 0.0f, 0.0f);
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (oldest == n_spp) break;
+                // ---- idle lanes take the next items, in lane order ----
+                const uint32_t limit = min(total, (oldest + rows) << 6);
+                const unsigned long long need = __ballot(!have);
+                if (!have) {
+                    const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi(uint32_t(need >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(need), 0u));
+                    if (idx < limit && ((amask >> (idx & 63u)) & 1ull)) {
+                        item = (((idx >> 6) & (rows - 1u)) << 6) | (idx & 63u);
+                        have = true;
+                        next_ray(true, idx & 63u, P.sample0 + s_first + (idx >> 6));
+                    }
+                }
+                next = min(next + uint32_t(__popcll(need)), limit);
+                if (have) {
+                    const int st = shade();
+                    if (st == 1) {
+                        cnt[RT_STAT_PATHS]++;
+                        have = false;
+                        atomicAdd(&s_rows[item >> 6], 1u);  // after the radiance stores of emit(): LDS operations of a wave stay in order
+                    } else if (st == 0) {
+                        next_ray(false, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
         }
         if (active) {
@@ -1156,7 +1168,8 @@ static void launch_mode(const KernelParams &P, int mode, bool lights, uint32_t b
     else launch_variant<STATS, MODE_GLOBAL>(P, lights, blocks, lds, stream);
 }
 
-// MODE_BVH: samples per chunk of the per-wave work pool (the radiance slots cost 768 B of LDS per sample and wave)
+// MODE_BVH: sample rows in the per-wave radiance ring (768 B of LDS per row and wave; measured on C4: 2 rows 77 ms, 4 rows 61 ms,
+// 8 rows — one workgroup fewer per CU — 72 ms)
 static uint32_t default_chunk() {
     static const int env = [] {
         const char *e = getenv("RTHIP_CHUNK");  // tuning knob; results do not depend on it
@@ -1181,14 +1194,13 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
     uint32_t lds = 0;
     if (mode == MODE_BVH) {
         if (P.bvh_levels == 0 || P.bvh_levels > RT_BVH_MAX_DEPTH) return hipErrorInvalidValue;
-        P.chunk = default_chunk();
-        if (P.chunk > P.spp) P.chunk = P.spp;
+        P.chunk = default_chunk();  // rows of the radiance ring: a power of two <= 16
         // only the first levels of the traversal stack live in LDS, deeper ones in private memory (a lane is that deep on
         // a few per cent of its pushes): 8 KB + 2 KB + 12 KB lets 7 workgroups share a CU's 160 KB
         uint32_t lds_levels = RT_BVH_LDS_LEVELS;
         if (const char *e = getenv("RTHIP_STACK_LDS")) lds_levels = uint32_t(atoi(e));  // tuning knob; results do not depend on it
         if (lds_levels < P.bvh_levels) P.bvh_levels = lds_levels;
-        lds = P.bvh_levels * 1024u + 2048u + 4u * 3u * 64u * 4u * P.chunk;
+        lds = P.bvh_levels * 1024u + 2048u + 4u * 3u * 64u * 4u * P.chunk + 4u * 16u * 4u;
     } else {
         P.chunk = P.spp;  // lane = pixel: one "chunk", no radiance slots
         P.bvh_levels = 0;
@@ -1196,9 +1208,6 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
     }
     if (lds > 65536u) return hipErrorInvalidValue;
     if (P.n_slices == 0 || P.slice_spp == 0 || (P.n_slices > 1 && (uint64_t(P.n_slices) * P.slice_spp < P.spp || !P.partial))) return hipErrorInvalidValue;
-    if (mode == MODE_BVH) {
-        while (P.chunk > 1 && P.slice_spp % P.chunk) P.chunk >>= 1;  // a chunk never straddles two sample groups
-    }
     // slice only when the launch would otherwise be too coarse to fill the GPU to its end (measured on the C2 frame:
     // whole frame 32 400 workgroups: slicing costs 3 %; 1/8 of it: unsliced 73 %, sliced 91 % of ideal); same image either way
     if (blocks >= RT_SLICE_BELOW_BLOCKS) P.n_slices = 1;
