@@ -180,7 +180,7 @@ __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
 #define RT_BVH_LEAF_LANES 16
 #endif
 #ifndef RT_BVH_YIELD_LANES
-#define RT_BVH_YIELD_LANES 24
+#define RT_BVH_YIELD_LANES 40
 #endif
 // Runs the traversal of every calling lane. YIELD: returns early (s.ref != RT_BVH_DONE on the
 // unfinished lanes) once RT_BVH_YIELD_LANES lanes of the wave have finished, so that the caller can

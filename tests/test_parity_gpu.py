@@ -261,6 +261,20 @@ def test_bvh_stack_split_does_not_change_the_image(monkeypatch):
     rt.close()
 
 
+@pytest.mark.parametrize("spp", [1, 3, 5, 17, 67])
+def test_bvh_sample_ring_any_sample_count(spp):
+    # the BVH kernel hands (pixel, sample) items to lanes and retires sample rows through a ring of 4 rows: row counts
+    # below, at and off multiples of the ring (and of the 64-sample groups), on an image whose tiles are partly outside
+    flat = flatten(presets.mesh_scene(4, 2))
+    rt = Raytracer.new(100, 52, seed=13)  # 100 x 52: the right and top tiles are cut
+    a = rt.render(flat, spp, max_depth=6, flags=abi.F_COUNT_STATS)
+    b = rt.render(flat, spp, max_depth=6, flags=abi.F_COUNT_STATS | abi.F_NO_BVH)
+    assert a.stats["node_tests"] > 0 and b.stats["node_tests"] == 0
+    assert a.stats["paths"] == b.stats["paths"] == 100 * 52 * spp and a.stats["rays"] == b.stats["rays"]
+    assert np.array_equal(a.accum, b.accum) and np.array_equal(a.rgba8, b.rgba8)
+    rt.close()
+
+
 def test_bvh_tie_break_duplicates():
     # 200 coincident sphere pairs: equal t everywhere; the larger index must win inside the BVH too
     rng = np.random.default_rng(2)
