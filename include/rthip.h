@@ -186,7 +186,9 @@ int rthip_create(int device, rthip_ctx **out_ctx);
 
 /* Flatten the scene to device SoA buffers (and a BVH for scenes of more than 64 spheres + triangles).
  * Replaces the borrowed `&[Box<dyn Shape>]` argument of generate_pixel (lib.rs:272). Waits for every pass still running
- * on the device (also those enqueued on caller streams by rthip_render_device) before touching the scene buffers. */
+ * on the device (also those enqueued on caller streams by rthip_render_device) before touching the scene buffers.
+ * RTHIP_E_BADARG for coordinates or radii that are not finite or exceed 1e18 in magnitude (their squares must stay finite
+ * in the device's FP32), zero radii, zero plane normals, material / texture indices out of range. */
 int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *scene);
 
 /* Replaces the `pub camera: Camera` field (lib.rs:240) read by emit_ray_at (camera.rs:43-50).

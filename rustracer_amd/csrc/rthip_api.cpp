@@ -106,7 +106,10 @@ inline double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline D3 cross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline D3 normalize(D3 a) { return mul(a, 1.0 / std::sqrt(dot(a, a))); }
 
-bool finite3(const double *p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
+// coordinates must survive the conversion to FP32 with their squares finite (|oc|^2, r^2): |x| <= 1e18
+constexpr double RT_COORD_MAX = 1e18;
+bool finite1(double v) { return std::isfinite(v) && std::fabs(v) <= RT_COORD_MAX; }
+bool finite3(const double *p) { return finite1(p[0]) && finite1(p[1]) && finite1(p[2]); }
 
 int owned_rows(const rthip_render_params *p, uint32_t *rows) {
     if (!p || !rows) return RTHIP_E_BADARG;
@@ -284,8 +287,8 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
         }
         for (uint64_t i = 0; i < s->n_spheres; i++) {
             if (s->spheres[i].material >= s->n_materials) return fail(ctx, RTHIP_E_BADARG, "sphere " + std::to_string(i) + ": material index out of range");
-            if (!finite3(s->spheres[i].center) || !std::isfinite(s->spheres[i].radius) || s->spheres[i].radius == 0.0)
-                return fail(ctx, RTHIP_E_BADARG, "sphere " + std::to_string(i) + ": non-finite centre or zero/non-finite radius");
+            if (!finite3(s->spheres[i].center) || !finite1(s->spheres[i].radius) || s->spheres[i].radius == 0.0)
+                return fail(ctx, RTHIP_E_BADARG, "sphere " + std::to_string(i) + ": centre or radius not finite (or beyond 1e18), or zero radius");
         }
         for (uint64_t i = 0; i < s->n_planes; i++) {
             if (s->planes[i].material >= s->n_materials) return fail(ctx, RTHIP_E_BADARG, "plane " + std::to_string(i) + ": material index out of range");
@@ -296,7 +299,7 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
         for (uint64_t i = 0; i < s->n_triangles; i++) {
             if (s->triangles[i].material >= s->n_materials) return fail(ctx, RTHIP_E_BADARG, "triangle " + std::to_string(i) + ": material index out of range");
             if (!finite3(s->triangles[i].v0) || !finite3(s->triangles[i].v1) || !finite3(s->triangles[i].v2))
-                return fail(ctx, RTHIP_E_BADARG, "triangle " + std::to_string(i) + ": non-finite vertex");
+                return fail(ctx, RTHIP_E_BADARG, "triangle " + std::to_string(i) + ": vertex not finite (or beyond 1e18)");
         }
         HIPCHK(ctx, hipSetDevice(ctx->device));
         // passes enqueued by rthip_render_device on the CALLER's streams may still be reading the scene buffers

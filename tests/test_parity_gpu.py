@@ -318,6 +318,12 @@ def test_error_behaviour():
     broken = flatten(presets.standalone_scene())
     broken.spheres["radius"][1] = 0.0
     assert lib.rthip_upload_scene(ctx, C.byref(broken.desc)) == abi.E_BADARG
+    # coordinates that FP32 cannot square: rejected at the boundary instead of rendering infinities
+    for bad_value in (1e19, float("inf"), float("nan")):
+        broken = flatten(presets.standalone_scene())
+        broken.spheres["center"][2][1] = bad_value
+        assert lib.rthip_upload_scene(ctx, C.byref(broken.desc)) == abi.E_BADARG and b"sphere 2" in lib.rthip_last_error(ctx)
+    assert lib.rthip_upload_scene(ctx, C.byref(flat.desc)) == 0
     # lights flag without lights
     cam = abi.Camera()
     lib.rthip_camera_lookat(-1.8, 1.0, 2.0, (C.c_double * 3)(0, 0, -1), C.byref(cam))
