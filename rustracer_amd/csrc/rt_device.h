@@ -16,7 +16,7 @@
 #include <stdint.h>
 
 #define RT_LDS_SPHERES 256u
-#define RT_CHUNK_BVH 4u
+#define RT_RING_ROWS 4u  // MODE_BVH: sample rows in a wave's radiance ring
 // samples per slice: 64, doubled until at most 16 slices cover spp; a function of spp alone, always a power of two
 #ifndef RT_SLICE_SPP
 #define RT_SLICE_SPP 64u
@@ -107,7 +107,7 @@ struct KernelParams {
     // scene
     uint32_t n_spheres, n_planes, n_tris, n_lights, n_bvh_nodes;
     uint32_t bvh_levels;  // traversal stack levels = depth of the tree
-    uint32_t chunk;       // samples per chunk of the per-wave work pool (set by rt_launch_render)
+    uint32_t ring_rows;   // MODE_BVH: sample rows in a wave's radiance ring, a power of two <= 16 (set by rt_launch_render)
     const rt_f4 *sph_geom;
     const rt_f4 *sph_shade;
     const rt_f4 *pln_geom;

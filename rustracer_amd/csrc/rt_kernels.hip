@@ -520,7 +520,7 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 //    tile (sky vs. mesh silhouette): with lane = pixel 80 % of the lanes idle. So a lane does NOT own
 //    a pixel while tracing: the tile's (pixel, sample) pairs are work items, item i = (pixel i & 63,
 //    sample i >> 6), and a lane whose path has ended takes the next item (ballot + prefix count, no
-//    atomics). Each finished item stores its radiance in its own LDS slot, in a ring of `P.chunk`
+//    atomics). Each finished item stores its radiance in its own LDS slot, in a ring of `P.ring_rows`
 //    sample rows; when the last path of the oldest row has ended lane p adds that row's slot of pixel p
 //    to its sum, so the samples are added in sample order exactly like the sequential loop of
 //    lib.rs:281-288,
@@ -529,7 +529,7 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 //
 // Dynamic LDS layout (bytes): [MODE_LDS: RT_LDS_SPHERES x 16 geometry | 3 x n_spheres x 16 shading]
 // [MODE_BVH: bvh_levels x 256 x 4 traversal stack | 4 waves x 64 x 8 per-pixel {RNG key, x | y << 16}
-// | 4 waves x 3 x 64*chunk x 4 radiance slots | 4 waves x 16 x 4 finished paths per ring row]; rt_launch_render computes the size.
+// | 4 waves x 3 x 64*ring_rows x 4 radiance slots | 4 waves x 16 x 4 finished paths per ring row]; rt_launch_render computes the size.
 // MODE_BVH is latency-bound (every node visit is a dependent 32-byte fetch that mostly hits L2): its speed follows the number
 // of resident waves (measured on C4/C5: 4 -> 5 -> 6 -> 7 waves per SIMD = 1.00 / 1.11 / 1.18 / 1.21), so the kernel is held to
 // 72 VGPRs (20 dwords of spills, outside the traversal loop) and its LDS to 22 KB per workgroup (see rt_launch_render).
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
 
     if (amask != 0ull) {
         uint2 *s_pix = s_pix_all + (wave << 6);
-        const uint32_t plane = P.chunk << 6;  // floats per colour plane of the wave's radiance slots
+        const uint32_t plane = P.ring_rows << 6;  // floats per colour plane of the wave's radiance slots
         float *s_L = s_L_all + wave * 3u * plane;
         uint32_t *s_rows = (uint32_t *)(s_L_all + 4u * 3u * plane) + (wave << 4);  // MODE_BVH: per ring slot, the paths that have ended
         rt_f4 pp_own;
@@ -963,8 +963,8 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             // Work items in hand-out order: item i = (pixel i & 63, sample i >> 6). The radiance of sample row r waits in ring
             // slot r & (rows - 1); the oldest row is retired (added to the pixels' sums, in sample order) as soon as its last
             // path has ended, and items are handed out up to `rows` rows ahead of it — the wave idles lanes for the slowest
-            // paths only at the very end of its samples, not once per chunk.
-            const uint32_t rows = P.chunk, total = n_spp << 6, expect = uint32_t(__popcll(amask));
+            // paths only at the very end of its samples, not once per group of rows.
+            const uint32_t rows = P.ring_rows, total = n_spp << 6, expect = uint32_t(__popcll(amask));
             if (lane < 16u) s_rows[lane] = 0u;  // paths that have ended, per ring slot
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1170,9 +1170,9 @@ static void launch_mode(const KernelParams &P, int mode, bool lights, uint32_t b
 
 // MODE_BVH: sample rows in the per-wave radiance ring (768 B of LDS per row and wave; measured on C4: 2 rows 77 ms, 4 rows 61 ms,
 // 8 rows — one workgroup fewer per CU — 72 ms)
-static uint32_t default_chunk() {
+static uint32_t default_ring_rows() {
     static const int env = [] {
-        const char *e = getenv("RTHIP_CHUNK");  // tuning knob; results do not depend on it
+        const char *e = getenv("RTHIP_RING_ROWS");  // tuning knob; results do not depend on it
         return e ? atoi(e) : 0;
     }();
     if (env > 0) {
@@ -1180,7 +1180,7 @@ static uint32_t default_chunk() {
         while (c * 2 <= uint32_t(env) && c < 16) c *= 2;  // a power of two, so that it divides the sample-group size
         return c;
     }
-    return RT_CHUNK_BVH;
+    return RT_RING_ROWS;
 }
 
 extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats, hipStream_t stream) {
@@ -1194,15 +1194,15 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
     uint32_t lds = 0;
     if (mode == MODE_BVH) {
         if (P.bvh_levels == 0 || P.bvh_levels > RT_BVH_MAX_DEPTH) return hipErrorInvalidValue;
-        P.chunk = default_chunk();  // rows of the radiance ring: a power of two <= 16
+        P.ring_rows = default_ring_rows();  // rows of the radiance ring: a power of two <= 16
         // only the first levels of the traversal stack live in LDS, deeper ones in private memory (a lane is that deep on
         // a few per cent of its pushes): 8 KB + 2 KB + 12 KB lets 7 workgroups share a CU's 160 KB
         uint32_t lds_levels = RT_BVH_LDS_LEVELS;
         if (const char *e = getenv("RTHIP_STACK_LDS")) lds_levels = uint32_t(atoi(e));  // tuning knob; results do not depend on it
         if (lds_levels < P.bvh_levels) P.bvh_levels = lds_levels;
-        lds = P.bvh_levels * 1024u + 2048u + 4u * 3u * 64u * 4u * P.chunk + 4u * 16u * 4u;
+        lds = P.bvh_levels * 1024u + 2048u + 4u * 3u * 64u * 4u * P.ring_rows + 4u * 16u * 4u;
     } else {
-        P.chunk = P.spp;  // lane = pixel: one "chunk", no radiance slots
+        P.ring_rows = 1;  // lane = pixel: no radiance slots
         P.bvh_levels = 0;
         lds = (mode == MODE_LDS) ? (RT_LDS_SPHERES + 3u * P.n_spheres) * 16u : 16u;
     }
