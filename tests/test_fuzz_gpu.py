@@ -77,3 +77,22 @@ def test_random_band_layouts_are_byte_identical(seed):
         rt.close()
     assert np.array_equal(img, full.rgba8) and np.array_equal(acc, full.accum), f"{w}x{h} bands of {band_rows} over {world}, {spp} spp x {passes}"
     whole.close()
+
+
+@pytest.mark.parametrize("seed", [3, 11, 42, 77, 1003, 1200])
+def test_random_geometry_bvh_equals_linear_scan(seed):
+    """tools/fuzz_bvh.py (400 scenes run on the MI355X in round 1): clouds of 65-6000 spheres / triangles at coordinate scales
+    1e-3..1e5, far from the origin, flat, with needles and duplicates — the traversal of the quantised tree returns exactly
+    what the linear scan returns (ray.rs:47-67), bit for bit"""
+    import fuzz_bvh
+    rng = np.random.default_rng(seed)
+    shapes, lights, eye, lookat, _ = fuzz_bvh.scene(rng)
+    flat = flatten(shapes, lights)
+    rt = Raytracer.new(97, 55, seed=seed)
+    rt.camera = Camera.new_lookat(eye[0], eye[1], eye[2], tuple(lookat))
+    fl = abi.F_COUNT_STATS | (abi.F_POINT_LIGHTS if lights else 0)
+    a = rt.render(flat, 3, max_depth=6, flags=fl)
+    b = rt.render(flat, 3, max_depth=6, flags=fl | abi.F_NO_BVH)
+    assert a.stats["node_tests"] > 0 and b.stats["node_tests"] == 0 and a.stats["rays"] == b.stats["rays"]
+    assert np.array_equal(a.accum.view(np.uint32), b.accum.view(np.uint32)) and np.array_equal(a.rgba8, b.rgba8)
+    rt.close()
