@@ -184,7 +184,7 @@ int rthip_device_count(int *out_count);
 /* Create a context on `device`. Replaces Raytracer::new (lib.rs:250). */
 int rthip_create(int device, rthip_ctx **out_ctx);
 
-/* Flatten the scene to device SoA buffers (and a BVH for scenes of more than 64 spheres + triangles).
+/* Flatten the scene to device SoA buffers (and a BVH once spheres + 4 x triangles exceed 96: below that the linear scan is faster).
  * Replaces the borrowed `&[Box<dyn Shape>]` argument of generate_pixel (lib.rs:272). Waits for every pass still running
  * on the device (also those enqueued on caller streams by rthip_render_device) before touching the scene buffers.
  * RTHIP_E_BADARG for coordinates or radii that are not finite or exceed 1e18 in magnitude (their squares must stay finite

@@ -402,7 +402,7 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
         std::vector<DevBvhNode> nodes;
         std::vector<uint32_t> prims;
         uint32_t bvh_levels = 0;
-        if (s->n_spheres + s->n_triangles > RT_BVH_THRESHOLD) bvh_levels = rt_build_bvh(s, nodes, prims);
+        if (rt_wants_bvh(s->n_spheres, s->n_triangles)) bvh_levels = rt_build_bvh(s, nodes, prims);
         if (bvh_levels > RT_BVH_MAX_DEPTH) return fail(ctx, RTHIP_E_INTERNAL, "BVH deeper than the traversal stack");
         std::vector<DevBvhNodeQ> qnodes;
         if (!rt_bvh_quantize(nodes, qnodes)) return fail(ctx, RTHIP_E_INTERNAL, "BVH node quantisation failed");
