@@ -43,8 +43,13 @@ def main():
     ap.add_argument("--band-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a one-GPU box: every rank renders on cuda:0 and the collectives run over gloo (checks the script, not the speed)")
     args = ap.parse_args()
 
+    if os.environ.get("BENCH_DUMP_AFTER"):  # debugging aid: print every thread's stack if the run is still going after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_DUMP_AFTER"]), exit=True)
     import torch
     import torch.distributed as dist
 
@@ -56,15 +61,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
+    device = 0 if args.rehearse else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
 
     flat = flatten(presets.standalone_scene())
-    rt = Raytracer.new(WIDTH, HEIGHT, seed=1, device=local_rank)
+    rt = Raytracer.new(WIDTH, HEIGHT, seed=1, device=device)
     rt.upload(flat)
-    br = BandRenderer(rt, rank, world, args.band_rows)
+    br = BandRenderer(rt, rank, world, args.band_rows, gather_on_host=args.rehearse)
 
     def barrier():
         if world > 1:
@@ -157,6 +166,8 @@ def main():
                 "flops_per_ray": flops_total / max(1.0, rays_total),
             },
         }
+        if args.rehearse:
+            out["rehearsal"] = "all ranks on cuda:0, gloo collectives: not a measurement"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat)
         if world == 1 and not args.no_parity:

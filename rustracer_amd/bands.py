@@ -63,6 +63,8 @@ class RowGatherer:
     def __call__(self, local, group=None):
         import torch.distributed as dist
 
+        if local.device != self.device:
+            local = local.to(self.device)  # host-side exchange (gloo has no GPU gather): synchronous copy on the current stream
         if self.padded is not None:
             self.padded[: self.own_rows].copy_(local)
             send = self.padded
@@ -88,7 +90,9 @@ class BandRenderer:
     """Per-rank driver: renders this rank's bands on its GPU into device tensors and gathers the
     RGBA8 image to rank 0."""
 
-    def __init__(self, raytracer, rank: int, world: int, band_rows: int = DEFAULT_BAND_ROWS):
+    def __init__(self, raytracer, rank: int, world: int, band_rows: int = DEFAULT_BAND_ROWS, gather_on_host: bool = False):
+        """gather_on_host: exchange the rows through host memory (for process groups whose backend cannot gather GPU tensors,
+        i.e. gloo); the frame then arrives on rank 0 as a CPU tensor."""
         import torch
 
         from .raytracer import make_params, owned_rows
@@ -103,7 +107,8 @@ class BandRenderer:
         # two frame buffers: the gather of frame k (on a side stream) overlaps the render of frame k + 1
         self._bufs = [torch.empty((self.rows, self.width, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
         self.rgba = self._bufs[0]
-        self._gatherer = None if world == 1 else RowGatherer(self.height, band_rows, rank, world, (self.width, 4), torch.uint8, dev)
+        self._gather_dev = torch.device("cpu") if gather_on_host else dev
+        self._gatherer = None if world == 1 else RowGatherer(self.height, band_rows, rank, world, (self.width, 4), torch.uint8, self._gather_dev)
         self._gather_stream = None if world == 1 else torch.cuda.Stream(device=dev)
         self._gathered = [None, None]  # per buffer: event "the gather that read it has finished"
         self._frame = 0
@@ -135,7 +140,7 @@ class BandRenderer:
         if self._gatherer is None and not force_collective:
             return buf
         if self._gatherer is None:
-            self._gatherer = RowGatherer(self.height, self.band_rows, self.rank, self.world, (self.width, 4), torch.uint8, buf.device)
+            self._gatherer = RowGatherer(self.height, self.band_rows, self.rank, self.world, (self.width, 4), torch.uint8, self._gather_dev)
             self._gather_stream = torch.cuda.Stream(device=buf.device)
         rendered = torch.cuda.Event()
         rendered.record(main)
