@@ -530,8 +530,8 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 // Dynamic LDS layout (bytes): [MODE_LDS: RT_LDS_SPHERES x 16 geometry | 3 x n_spheres x 16 shading]
 // [MODE_BVH: bvh_levels x 256 x 4 traversal stack | 4 waves x 64 x 8 per-pixel {RNG key, x | y << 16}
 // | 4 waves x 3 x 64*ring_rows x 4 radiance slots | 4 waves x 16 x 4 finished paths per ring row]; rt_launch_render computes the size.
-// MODE_BVH is latency-bound (every node visit is a dependent 32-byte fetch that mostly hits L2): its speed follows the number
-// of resident waves (measured on C4/C5: 4 -> 5 -> 6 -> 7 waves per SIMD = 1.00 / 1.11 / 1.18 / 1.21), so the kernel is held to
+// MODE_BVH needs resident waves to cover its node fetches (every visit is a dependent, divergent 32-byte fetch): its speed follows
+// the number of waves (measured on C4/C5: 4 -> 5 -> 6 -> 7 waves per SIMD = 1.00 / 1.11 / 1.18 / 1.21), so the kernel is held to
 // 72 VGPRs (20 dwords of spills, outside the traversal loop) and its LDS to 22 KB per workgroup (see rt_launch_render).
 #ifndef RT_BVH_LIGHT_WAVES
 #define RT_BVH_LIGHT_WAVES 5
