@@ -533,6 +533,9 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 // MODE_BVH needs resident waves to cover its node fetches (every visit is a dependent, divergent 32-byte fetch): its speed follows
 // the number of waves (measured on C4/C5: 4 -> 5 -> 6 -> 7 waves per SIMD = 1.00 / 1.11 / 1.18 / 1.21), so the kernel is held to
 // 72 VGPRs (20 dwords of spills, outside the traversal loop) and its LDS to 22 KB per workgroup (see rt_launch_render).
+#ifndef RT_SCAN_LIGHT_WAVES
+#define RT_SCAN_LIGHT_WAVES 5
+#endif
 #ifndef RT_BVH_LIGHT_WAVES
 #define RT_BVH_LIGHT_WAVES 5
 #endif
@@ -540,7 +543,7 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 #define RT_BVH_WAVES 7
 #endif
 template <bool STATS, int MODE, bool LIGHTS>
-__global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_BVH_LIGHT_WAVES : 5) : (MODE == MODE_BVH ? RT_BVH_WAVES : 7))) void render_kernel(const KernelParams P) {
+__global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_BVH_LIGHT_WAVES : RT_SCAN_LIGHT_WAVES) : (MODE == MODE_BVH ? RT_BVH_WAVES : 7))) void render_kernel(const KernelParams P) {
     constexpr bool POOL = MODE == MODE_BVH;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     rt_f4 *s_geom_mem = (rt_f4 *)s_dyn;

