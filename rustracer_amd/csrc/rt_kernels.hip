@@ -201,8 +201,11 @@ __device__ __forceinline__ bool slab_from_t(float ax, float bx, float ay, float 
     return tn <= tf && tn <= limit && tf >= tmin;
 }
 
-template <bool STATS, bool ANY, bool YIELD>
-__device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uint32_t self, HitRec &h, BvhState &s, BvhDeep &deep, uint32_t *cnt, uint32_t *s_stack) {
+// ANY: 0 = closest-hit query, 1 = any-hit query, 2 = per lane (any_lane): closest-hit and shadow rays of a wave walk the tree together
+template <bool STATS, int ANY, bool YIELD>
+__device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uint32_t self, HitRec &h, BvhState &s, BvhDeep &deep, uint32_t *cnt, uint32_t *s_stack,
+                                        bool any_lane = false) {
+    const bool any = ANY == 2 ? any_lane : (ANY == 1);
     const uint4 *nodes = (const uint4 *)P.bvh_nodes;  // DevBvhNodeQ: 2 x 16 bytes
     uint32_t ref = s.ref;
     int sp = s.sp;
@@ -245,7 +248,7 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
           if (ref < RT_BVH_DONE) {
             const uint4 na = nodes[2 * ref], nb = nodes[2 * ref + 1];  // {frame x, y, z, ref0} {q x, y, z, ref1}
             if (STATS) cnt[RT_STAT_NODE] += 2;
-            const float limit = ANY ? r.tmax : fminf(h.t, r.tmax);
+            const float limit = any ? r.tmax : fminf(h.t, r.tmax);
             // per axis: plane distance t = (o + q*step)/d - origin/d = q * (step/d) + (o/d - origin/d)
             const float Ax = ldexpf(s.inv_d.x, __builtin_amdgcn_sbfe(int(na.x), 0, 8)), Bx = fmaf(__uint_as_float(na.x), s.inv_d.x, s.noi.x);
             const float Ay = ldexpf(s.inv_d.y, __builtin_amdgcn_sbfe(int(na.y), 0, 8)), By = fmaf(__uint_as_float(na.y), s.inv_d.y, s.noi.y);
@@ -291,8 +294,12 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
                     float t;
                     bool ok = hit_sphere(rt_f4{a.x, a.y, a.z, b.x}, r, id == self, t);
                     if (STATS) cnt[RT_STAT_SPHERE]++;
-                    if (ANY) {
+                    if (ANY == 1) {
                         found |= ok;
+                    } else if (ANY == 2) {
+                        found |= ok && any;
+                        ok = ok && !any;
+                        RT_TAKE_ANY_ORDER(ok, t, id, (void)0)
                     } else {
                         RT_TAKE_ANY_ORDER(ok, t, id, (void)0)
                     }
@@ -300,14 +307,18 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
                     float t, b1, b2;
                     bool ok = hit_tri(a, b, c, r, t, b1, b2);
                     if (STATS) cnt[RT_STAT_TRI]++;
-                    if (ANY) {
+                    if (ANY == 1) {
                         found |= ok;
+                    } else if (ANY == 2) {
+                        found |= ok && any;
+                        ok = ok && !any;
+                        RT_TAKE_ANY_ORDER(ok, t, id, (h.b1 = b1, h.b2 = b2))
                     } else {
                         RT_TAKE_ANY_ORDER(ok, t, id, (h.b1 = b1, h.b2 = b2))
                     }
                 }
             }
-            if (sp > 0 && !(ANY && found)) {
+            if (sp > 0 && !(any && found)) {
                 ref = pop();
             } else {
                 ref = RT_BVH_DONE;
@@ -407,7 +418,7 @@ __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &
         BvhState bs;
         BvhDeep deep;
         bvh_begin(r, bs);
-        bvh_run<STATS, false, false>(P, r, self, h, bs, deep, cnt, s_stack);
+        bvh_run<STATS, 0, false>(P, r, self, h, bs, deep, cnt, s_stack);
     }
     if (STATS) cnt[RT_STAT_PLANE] += P.n_planes;
     return h;
@@ -440,7 +451,7 @@ __device__ __forceinline__ bool occluded(const KernelParams &P, const Ray &r, ui
         BvhState bs;
         BvhDeep deep;
         bvh_begin(r, bs);
-        occ = bvh_run<STATS, true, false>(P, r, self, dummy, bs, deep, cnt, s_stack);
+        occ = bvh_run<STATS, 1, false>(P, r, self, dummy, bs, deep, cnt, s_stack);
     }
     return occ;
 }
@@ -666,6 +677,47 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 grp = grp + L;  // lib.rs:287
             }
         };
+        // MODE_BVH + point lights: the direct term of the surface shade() found, one light at a time. Finds the next light that
+        // can contribute, starts its shadow ray (the lane is then "parked": 2) or, after the last light, closes the term (0).
+        uint32_t lit = 0;  // index + 1 of the light whose shadow ray this lane is tracing, 0 = none
+        f3 lsum = mk3(0.0f, 0.0f, 0.0f);
+        float lsc = 0.0f;
+        auto next_light = [&]() -> int {
+            for (; lit <= P.n_lights; lit++) {
+                const DevMaterial m = P.materials[sf.mat];
+                const DevLight lt = P.lights[lit - 1u];
+                const f3 to_light = mk3(lt.px - p.x, lt.py - p.y, lt.pz - p.z);
+                const float dist2 = dot(to_light, to_light);
+                const float rdist = fast_rsq(dist2);
+                const f3 ldir = to_light * rdist;
+                float w;
+                if (sf.kind == RTHIP_MAT_LAMBERTIAN)
+                    w = fmaxf(0.0f, dot(sf.n, ldir));
+                else
+                    w = (m.shininess > 0.0f) ? __powf(fmaxf(0.0f, dot(refl, ldir)), m.shininess) : 0.0f;
+                if (!(w > 0.0f)) continue;
+                cnt[RT_STAT_RAYS]++;
+                if (STATS) cnt[RT_STAT_SHADOW]++;
+                // the shadow ray replaces the lane's ray: next_ray() builds the scattered ray from p, the surface and refl alone
+                // (lit surfaces are not dielectric)
+                r.o = p, r.d = ldir;
+                const float dist = dist2 * rdist;
+                r.tmin = RT_T_MIN * dist, r.tmax = dist;
+                lsc = w * fast_rcp(dist2);
+                bool occ = false;
+                float t;
+                for (uint32_t i = 0; i < P.n_planes; i++) occ |= hit_plane(P.pln_geom[4 * i], r, t);
+                if (STATS) cnt[RT_STAT_PLANE] += P.n_planes;
+                if (occ) continue;
+                bvh_begin(r, bs);
+                tracing = true;
+                return 2;
+            }
+            lit = 0u;
+            Ld = Ld + T * lsum;
+            T = T * sf.tm;  // scatter (as at the end of shade())
+            return 0;
+        };
         auto shade = [&]() -> int {
             bool done;
             if (dead) {  // None -> new_color alone, ray.rs:80
@@ -684,9 +736,20 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     }
                 }
                 if (tracing) {
-                    bvh_run<STATS, false, true>(P, r, self, h, bs, deep, cnt, s_stack);
+                    bool blocked;
+                    if (LIGHTS) blocked = bvh_run<STATS, 2, true>(P, r, lit ? h.shape : self, h, bs, deep, cnt, s_stack, lit != 0u);
+                    else blocked = bvh_run<STATS, 0, true>(P, r, self, h, bs, deep, cnt, s_stack);
                     if (bs.ref != RT_BVH_DONE) return 2;  // parked: the finished lanes of the wave shade and fetch new work
                     tracing = false;
+                    if (LIGHTS && lit) {  // the shadow ray of light lit - 1 has left the tree
+                        if (!blocked) {
+                            const DevMaterial m = P.materials[sf.mat];
+                            const DevLight lt = P.lights[lit - 1u];
+                            lsum = lsum + mk3(m.ar * lt.ir, m.ag * lt.ig, m.ab * lt.ib) * lsc;
+                        }
+                        lit++;
+                        return next_light();
+                    }
                 }
             } else {
                 h.shape = RT_NONE;
@@ -771,7 +834,14 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 } else {
                     cosi = dot(r.d, sf.n);
                     refl = fma3(sf.n, -2.0f * cosi, r.d);  // metal.rs:27-29, dielectric.rs:28-30 (unit incoming direction)
-                    if (LIGHTS && sf.kind != RTHIP_MAT_DIELECTRIC) {
+                    if (LIGHTS && POOL && sf.kind != RTHIP_MAT_DIELECTRIC) {
+                        // the work-pool variant traces its shadow rays like any other ray of the pool (resumable, together with the
+                        // closest-hit rays of the other lanes); same terms in the same order as the loop below
+                        lsum = mk3(0.0f, 0.0f, 0.0f);
+                        lit = 1u;
+                        return next_light();
+                    }
+                    if (LIGHTS && !POOL && sf.kind != RTHIP_MAT_DIELECTRIC) {
                         // extension (RTHIP_F_POINT_LIGHTS): Lambert N.L on Lambertian, Phong (R.L)^s on Metal, one shadow ray per light
                         const DevMaterial m = P.materials[sf.mat];
                         f3 sum = mk3(0.0f, 0.0f, 0.0f);
