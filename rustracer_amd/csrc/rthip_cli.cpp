@@ -2,7 +2,10 @@
 // reference's standalone scene (standalone/src/main.rs:66-89) with the mirrored constructors, renders it
 // on the GPU through a PixelRenderer (the `World` framebuffer of standalone/src/renderers/pixels.rs:205-262,
 // reduced to a byte buffer), writes a PPM and prints one JSON line of statistics.
-//   rthip_cli [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--texture path.rgb8.z] [--out image.ppm]
+//   rthip_cli [--scene standalone|wasm|grid] [--grid N] [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--texture path.rgb8.z]
+//             [--out image.ppm]
+//             --scene wasm: the three metal spheres of wasm/src/lib.rs:90-105; grid: N x N small spheres + ground + a quad (extension
+//             shapes; big enough N goes through the BVH) — tests/test_cli_gpu.py builds the same scenes through the Python layer
 //             [--passes P]   P > 0: the standalone window's progressive loop (standalone/src/main.rs:99-102) — P adaptive
 //                            passes of N samples with the convergence rule of lib.rs:276-313 instead of one batch
 #include <cstdio>
@@ -13,6 +16,46 @@
 #include "raytracer_hip.hpp"
 
 using namespace raytracer_hip;
+
+static Scene standalone_scene(const std::string &texture) {  // standalone/src/main.rs:66-89
+    return {
+        Sphere::create({-1.01, 0.0, -1.0}, 0.5, Dielectric::create({1.0, 0.8, 0.80}, 1.05)),
+        Sphere::create({0.0, -100.5, -1.0}, 100.0, Lambertian::new_from_hex(0x007070)),
+        Sphere::create({1.0, 0.0, -1.0}, 0.5, Metal::create({0.8, 0.8, 0.8}, 0.1)),
+        Sphere::create({-0.0, 0.0, -1.0}, 0.5, Texture::load_from_file(texture, 1.0)),
+    };
+}
+
+static Scene wasm_scene() {  // wasm/src/lib.rs:90-105
+    return {
+        Sphere::create({0.0, 0.0, -1.0}, 0.5, Metal::create({0.8, 0.8, 0.8}, 0.0)),
+        Sphere::create({0.0, -100.5, -1.0}, 100.0, Metal::create({0.8, 0.8, 0.8}, 0.0)),
+        Sphere::create({0.5, -0.4, -0.85}, 0.1, Metal::create({0.8, 0.8, 0.8}, 0.0)),
+    };
+}
+
+// n x n small spheres of the three scattering materials over the ground sphere, and a quad of two triangles behind them
+static Scene grid_scene(int n) {
+    Scene s;
+    s.push_back(Sphere::create({0.0, -100.5, -1.0}, 100.0, Lambertian::new_from_hex(0x007070)));
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            const Vector3 c = {(i - n * 0.5) * 0.6, -0.3 + 0.05 * ((i * 7 + j * 3) % 5), -1.0 - j * 0.6};
+            const double radius = 0.1 + 0.02 * ((i + 2 * j) % 4);
+            std::shared_ptr<Material> m;
+            switch ((i + j) % 3) {
+                case 0: m = Lambertian::create({0.2 + 0.1 * (i % 5), 0.5, 0.3 + 0.1 * (j % 4)}); break;
+                case 1: m = Metal::create({0.8, 0.8, 0.8}, 0.1 * ((i + j) % 4)); break;
+                default: m = Dielectric::create({1.0, 1.0, 1.0}, 1.5);
+            }
+            s.push_back(Sphere::create(c, radius, m));
+        }
+    auto wall = Lambertian::create({0.7, 0.6, 0.2});
+    const double z = -1.5 - n * 0.6;
+    s.push_back(Triangle::create({-4.0, -0.5, z}, {4.0, -0.5, z}, {4.0, 2.0, z}, wall));
+    s.push_back(Triangle::create({-4.0, -0.5, z}, {4.0, 2.0, z}, {-4.0, 2.0, z}, wall));
+    return s;
+}
 
 struct World : PixelRenderer {  // standalone/src/renderers/pixels.rs:205-262
     uint32_t width, height;
@@ -30,7 +73,8 @@ struct World : PixelRenderer {  // standalone/src/renderers/pixels.rs:205-262
 
 int main(int argc, char **argv) {
     uint32_t width = 960, height = 540, spp = 16, depth = 50, seed = 1, passes = 0;  // standalone/src/main.rs:51-52, ray.rs:44
-    std::string out, texture = "tests/golden/textures/bergsjostolen.rgb8.z";
+    std::string out, texture = "tests/golden/textures/bergsjostolen.rgb8.z", scene_name = "standalone";
+    int grid = 12;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i];
         if (k == "--width") width = std::atoi(argv[i + 1]);
@@ -40,16 +84,17 @@ int main(int argc, char **argv) {
         else if (k == "--seed") seed = std::atoi(argv[i + 1]);
         else if (k == "--passes") passes = std::atoi(argv[i + 1]);
         else if (k == "--texture") texture = argv[i + 1];
+        else if (k == "--scene") scene_name = argv[i + 1];
+        else if (k == "--grid") grid = std::atoi(argv[i + 1]);
         else if (k == "--out") out = argv[i + 1];
         else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     try {
-        Scene scene = {
-            Sphere::create({-1.01, 0.0, -1.0}, 0.5, Dielectric::create({1.0, 0.8, 0.80}, 1.05)),
-            Sphere::create({0.0, -100.5, -1.0}, 100.0, Lambertian::new_from_hex(0x007070)),
-            Sphere::create({1.0, 0.0, -1.0}, 0.5, Metal::create({0.8, 0.8, 0.8}, 0.1)),
-            Sphere::create({-0.0, 0.0, -1.0}, 0.5, Texture::load_from_file(texture, 1.0)),
-        };
+        Scene scene;
+        if (scene_name == "standalone") scene = standalone_scene(texture);
+        else if (scene_name == "wasm") scene = wasm_scene();
+        else if (scene_name == "grid" && grid > 0 && grid <= 1000) scene = grid_scene(grid);
+        else { std::fprintf(stderr, "unknown scene %s\n", scene_name.c_str()); return 2; }
         SceneDesc desc(scene);
         HipRaytracer rt(width, height, seed);
         rt.upload(desc);

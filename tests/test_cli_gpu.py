@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from rustracer_amd import Raytracer, presets
+from rustracer_amd import Dielectric, Lambertian, Metal, Raytracer, Sphere, Triangle, presets
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -51,6 +51,48 @@ def test_cli_progressive_adaptive_passes(tmp_path):
         paths += res.stats["paths"]
     assert info["paths"] == paths == info["set_pixel_calls"]   # spp = 1: one set_pixel per traced pixel
     assert info["final_pixels"] == res.stats["pixels_final"] == info["final_set_pixel_calls"] > 0
+    tok = out.read_text().split()
+    ppm = np.array(tok[4:], dtype=np.uint8).reshape(h, w, 3)
+    assert np.array_equal(ppm, res.rgba8[::-1, :, :3])
+    rt.close()
+
+
+def _grid_scene(n):
+    """the scene of `rthip_cli --scene grid --grid n` (rthip_cli.cpp: grid_scene), through the Python constructors"""
+    s = [Sphere.new((0.0, -100.5, -1.0), 100.0, Lambertian.new_from_hex(0x007070))]
+    for i in range(n):
+        for j in range(n):
+            c = ((i - n * 0.5) * 0.6, -0.3 + 0.05 * ((i * 7 + j * 3) % 5), -1.0 - j * 0.6)
+            radius = 0.1 + 0.02 * ((i + 2 * j) % 4)
+            k = (i + j) % 3
+            if k == 0:
+                m = Lambertian.new((0.2 + 0.1 * (i % 5), 0.5, 0.3 + 0.1 * (j % 4)))
+            elif k == 1:
+                m = Metal.new((0.8, 0.8, 0.8), 0.1 * ((i + j) % 4))
+            else:
+                m = Dielectric.new((1.0, 1.0, 1.0), 1.5)
+            s.append(Sphere.new(c, radius, m))
+    wall = Lambertian.new((0.7, 0.6, 0.2))
+    z = -1.5 - n * 0.6
+    s.append(Triangle.new((-4.0, -0.5, z), (4.0, -0.5, z), (4.0, 2.0, z), wall))
+    s.append(Triangle.new((-4.0, -0.5, z), (4.0, 2.0, z), (-4.0, 2.0, z), wall))
+    return s
+
+
+@pytest.mark.parametrize("name,grid", [("wasm", 0), ("grid", 4), ("grid", 14)])
+def test_cli_scene_presets(tmp_path, name, grid):
+    """the other scenes of the C++ front-end: wasm/src/lib.rs:90-105, and sphere grids with a triangle quad (grid 4: LDS scan,
+    grid 14: 197 spheres + 2 triangles through the BVH) — byte-identical to the same scene built with the Python constructors"""
+    w, h, spp, depth, seed = 160, 90, 2, 8, 3
+    out = tmp_path / "img.ppm"
+    r = subprocess.run([CLI, "--scene", name, "--grid", str(max(grid, 1)), "--width", str(w), "--height", str(h), "--spp", str(spp), "--depth", str(depth),
+                        "--seed", str(seed), "--out", str(out)], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout)
+    scene = presets.wasm_scene() if name == "wasm" else _grid_scene(grid)
+    rt = Raytracer.new(w, h, seed=seed)
+    res = rt.render(scene, spp, max_depth=depth)
+    assert info["rays"] == res.stats["rays"] and info["paths"] == w * h * spp
     tok = out.read_text().split()
     ppm = np.array(tok[4:], dtype=np.uint8).reshape(h, w, 3)
     assert np.array_equal(ppm, res.rgba8[::-1, :, :3])
