@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RTHIP_ABI_VERSION 2
+#define RTHIP_ABI_VERSION 3
 
 typedef enum rthip_status {
     RTHIP_OK = 0,
@@ -43,7 +43,8 @@ typedef enum rthip_status {
     RTHIP_E_OOM = -3,
     RTHIP_E_NODEVICE = -4,
     RTHIP_E_STATE = -5, /* call order: render before scene/camera upload */
-    RTHIP_E_INTERNAL = -6
+    RTHIP_E_INTERNAL = -6,
+    RTHIP_E_RCCL = -7 /* rthip_group_*: an RCCL call failed */
 } rthip_status;
 
 /* ---- materials: raytracer_core/src/materials/{lambertian_diffuse,metal,dielectric,texture}.rs ---- */
@@ -149,7 +150,7 @@ typedef struct rthip_render_params {
     uint32_t width;       /* full image width  (u = (x+xi)/(width-1),  lib.rs:282-283) */
     uint32_t height;      /* full image height (v = (y+xi)/(height-1), lib.rs:284-285) */
     uint32_t spp;         /* samples per pixel of THIS pass (generate_pixel's `samples`); a running sum holds at most 2^24 */
-    uint32_t max_depth;   /* 50 = reference (ray.rs:44) */
+    uint32_t max_depth;   /* 50 = reference (ray.rs:44); at most 255 (the counter RNG has 256 slots per sample) */
     uint32_t seed;        /* counter-RNG seed (replaces the entropy-seeded SmallRng) */
     uint32_t flags;       /* RTHIP_F_* */
     uint32_t band_rows;   /* rows per band R; 0 = the whole image is one band owned by this context */
@@ -174,6 +175,8 @@ typedef struct rthip_stats {
     double d2h_ms;         /* device->host copy of the outputs (rthip_render only) */
     uint64_t pixels_traced; /* RTHIP_F_ADAPTIVE: pixels that received samples this pass (all owned pixels otherwise) */
     uint64_t pixels_final;  /* RTHIP_F_ADAPTIVE: owned pixels that are Final after this pass */
+    double gather_ms;       /* rthip_group_render only: from the end of device 0's render to the assembled frame on device 0
+                               (waits for the slowest device, RCCL gather, de-interleave) */
 } rthip_stats;
 
 typedef struct rthip_ctx rthip_ctx;
@@ -219,6 +222,8 @@ int rthip_render(rthip_ctx *ctx, const rthip_render_params *params, uint8_t *rgb
  * null stream) without synchronising. d_rgba8 / d_accum are device pointers of the sizes above
  * (either may be NULL). Used by callers that own device buffers (the multi-GPU gather, benches).
  * kernel_ms in `stats` is filled only if `stats` is non-NULL, which makes the call synchronous.
+ * Passes of one context share its running sum and work buffers: a pass enqueued on a different stream
+ * than the previous pass of the context first waits (on the device) for that pass.
  */
 int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *params, void *d_rgba8, void *d_accum,
                         void *hip_stream, rthip_stats *stats);
@@ -231,7 +236,12 @@ int rthip_reset_accum(rthip_ctx *ctx);
  * byte per pixel (RTHIP_STATUS_*), owned_rows*width bytes in the layout of the image outputs. This is what
  * the reference hands to PixelRenderer::set_pixel beside r,g,b (standalone/src/renderers/pixels.rs:254 draws it).
  * same_color_count_out (nullable): PixelCache.same_color_count (lib.rs:71). RTHIP_E_STATE if no adaptive pass ran. */
-int rthip_pixel_status(rthip_ctx *ctx, uint8_t *status_out, uint8_t *same_color_count_out);
+int rthip_pixel_status(rthip_ctx *ctx, uint8_t *status_out, uint8_t *same_color_count_out, uint64_t capacity_pixels);
+
+/* Layout of the context's running sum (PixelCache.incremental_raw_light / nb_samples, lib.rs:67-73) after the last pass:
+ * owned rows, width, samples per pixel so far (all 0 after a reset / camera / scene change). Sizes the buffers of
+ * rthip_pixel_status, whose capacity_pixels (the pixels each buffer can hold) must be >= rows*width (RTHIP_E_BADARG). */
+int rthip_accum_layout(rthip_ctx *ctx, uint32_t *out_rows, uint32_t *out_width, uint64_t *out_nb_samples);
 
 /* Optional: page-locked host memory for the image outputs of rthip_render. The reference's framebuffer is a plain Vec
  * (standalone/src/renderers/pixels.rs:190-209); a pageable destination makes the device->host copy of a 4K RGBA8 frame
@@ -263,6 +273,37 @@ double rthip_algorithmic_flops(const rthip_stats *stats);
 #define RTHIP_FLOPS_DIELECTRIC 73.0   /* throughput 3, reflect/refract/schlick 70      dielectric.rs:28-98 */
 #define RTHIP_FLOPS_TEXTURE 15.0      /* throughput 3, uv + wrap 12 (atan2/acos = 1 each)   sphere.rs:67-73, texture.rs:32-57 */
 #define RTHIP_FLOPS_TONEMAP 12.0      /* per pixel: 4 per channel                      lib.rs:294-298 */
+
+/*
+ * ---- single-process multi-GPU ----------------------------------------------------------------
+ * The reference's caller is ONE render thread that wants the whole frame from one call (standalone/src/main.rs:65,99-102;
+ * wasm/src/lib.rs:112-123). A group owns one context + stream per listed device; the image is split into interleaved row
+ * bands (band b = rows [b*R, (b+1)*R), device b mod ndev), the scene is replicated, and the bands are gathered to the first
+ * device over RCCL (ncclCommInitAll once in rthip_group_create; grouped ncclSend/ncclRecv per frame, one transfer per xGMI
+ * link), de-interleaved there and copied out. The RNG is keyed by the absolute pixel index, so the frame is byte-identical
+ * to rthip_render's for any device count. No counterpart in the reference (it has no device or process boundary).
+ */
+typedef struct rthip_group rthip_group;
+enum {
+    RTHIP_GROUP_F_PEER_COPY = 1u << 0, /* gather with hipMemcpyPeerAsync instead of RCCL (also allows listing a device more than once:
+                                          rehearsals of an N-way split on fewer GPUs) */
+    RTHIP_GROUP_F_FORCE_RCCL = 1u << 1 /* use RCCL also for a single device (the gather is then a self-transfer) */
+};
+int rthip_group_create(const int *devices, int ndev, uint32_t flags, rthip_group **out_group);
+int rthip_group_upload_scene(rthip_group *group, const rthip_scene_desc *scene); /* rthip_upload_scene on every device */
+int rthip_group_set_camera(rthip_group *group, const rthip_camera *camera);
+/* One pass over the WHOLE frame. params: band_rows = rows per band (0 = 8), band_first / band_stride must be 0;
+ * RTHIP_F_ADAPTIVE is not supported. rgba8_out: height*width*4 bytes, accum_out: height*width*3 floats (either may be NULL),
+ * both host buffers, row 0 = bottom. stats (nullable): counters summed over devices, kernel_ms = the slowest device,
+ * gather_ms. RTHIP_F_ACCUMULATE works as in rthip_render (every device keeps the running sum of its rows). */
+int rthip_group_render(rthip_group *group, const rthip_render_params *params, uint8_t *rgba8_out, float *accum_out, rthip_stats *stats);
+int rthip_group_reset_accum(rthip_group *group);
+int rthip_group_size(const rthip_group *group);
+rthip_ctx *rthip_group_context(rthip_group *group, int index); /* e.g. rthip_pick on device 0; owned by the group */
+const char *rthip_group_last_error(const rthip_group *group);
+void rthip_group_destroy(rthip_group *group);
+/* The row map of the band split: image row y is local row *out_local_row of device *out_rank. */
+int rthip_band_row_owner(uint32_t band_rows, uint32_t ndev, uint32_t y, uint32_t *out_rank, uint32_t *out_local_row);
 
 const char *rthip_last_error(const rthip_ctx *ctx);
 const char *rthip_status_string(int status);

@@ -13,12 +13,14 @@ fn main() {
         .arg(csrc.join("rt_kernels.hip"))
         .arg(csrc.join("rthip_api.cpp"))
         .arg(csrc.join("rt_bvh.cpp"))
+        .arg(csrc.join("rthip_group.cpp"))
+        .arg("-ldl") // RCCL is dlopen'ed by the first multi-device group
         .status()
         .expect("failed to run hipcc");
     assert!(status.success(), "hipcc failed");
     println!("cargo:rustc-link-search=native={}", out.display());
     println!("cargo:rustc-link-lib=dylib=rthip");
-    for f in &["rt_kernels.hip", "rthip_api.cpp", "rt_bvh.cpp", "rt_device.h", "rt_rng.h", "rt_bvh.h"] {
+    for f in &["rt_kernels.hip", "rthip_api.cpp", "rt_bvh.cpp", "rthip_group.cpp", "rt_device.h", "rt_rng.h", "rt_bvh.h"] {
         println!("cargo:rerun-if-changed={}", csrc.join(f).display());
     }
     println!("cargo:rerun-if-changed={}", root.join("include").join("rthip.h").display());

@@ -1,5 +1,5 @@
 //! #[repr(C)] mirrors of include/rthip.h and the extern "C" entry points. Keep in sync with the header
-//! (RTHIP_ABI_VERSION = 2); tests/test_abi.py pins the struct sizes the same way.
+//! (RTHIP_ABI_VERSION = 3); tests/test_abi.py pins the struct sizes the same way.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -16,6 +16,8 @@ pub const RTHIP_F_ADAPTIVE: u32 = 1 << 4;
 pub const RTHIP_STATUS_NOT_STARTED: u8 = 0;
 pub const RTHIP_STATUS_UNSTABLE: u8 = 2;
 pub const RTHIP_STATUS_FINAL: u8 = 3;
+pub const RTHIP_GROUP_F_PEER_COPY: u32 = 1 << 0;
+pub const RTHIP_GROUP_F_FORCE_RCCL: u32 = 1 << 1;
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct rthip_material { pub kind: u32, pub texture: u32, pub albedo: [f64; 3], pub param: f64, pub shininess: f64 }
@@ -51,8 +53,10 @@ pub struct rthip_stats {
     pub hits: [u64; 4], pub sky_evals: u64, pub shadow_rays: u64, pub rows: u64, pub nb_samples: u64,
     pub kernel_ms: f64, pub d2h_ms: f64,
     pub pixels_traced: u64, pub pixels_final: u64,
+    pub gather_ms: f64,
 }
 pub enum rthip_ctx {}
+pub enum rthip_group {}
 
 extern "C" {
     pub fn rthip_abi_version() -> c_int;
@@ -67,7 +71,19 @@ extern "C" {
     pub fn rthip_render_device(ctx: *mut rthip_ctx, params: *const rthip_render_params, d_rgba8: *mut c_void, d_accum: *mut c_void,
                                hip_stream: *mut c_void, stats: *mut rthip_stats) -> c_int;
     pub fn rthip_reset_accum(ctx: *mut rthip_ctx) -> c_int;
-    pub fn rthip_pixel_status(ctx: *mut rthip_ctx, status_out: *mut u8, same_color_count_out: *mut u8) -> c_int;
+    pub fn rthip_pixel_status(ctx: *mut rthip_ctx, status_out: *mut u8, same_color_count_out: *mut u8, capacity_pixels: u64) -> c_int;
+    pub fn rthip_accum_layout(ctx: *mut rthip_ctx, out_rows: *mut u32, out_width: *mut u32, out_nb_samples: *mut u64) -> c_int;
+    pub fn rthip_group_create(devices: *const c_int, ndev: c_int, flags: u32, out_group: *mut *mut rthip_group) -> c_int;
+    pub fn rthip_group_upload_scene(group: *mut rthip_group, scene: *const rthip_scene_desc) -> c_int;
+    pub fn rthip_group_set_camera(group: *mut rthip_group, camera: *const rthip_camera) -> c_int;
+    pub fn rthip_group_render(group: *mut rthip_group, params: *const rthip_render_params, rgba8_out: *mut u8, accum_out: *mut f32,
+                              stats: *mut rthip_stats) -> c_int;
+    pub fn rthip_group_reset_accum(group: *mut rthip_group) -> c_int;
+    pub fn rthip_group_size(group: *const rthip_group) -> c_int;
+    pub fn rthip_group_context(group: *mut rthip_group, index: c_int) -> *mut rthip_ctx;
+    pub fn rthip_group_last_error(group: *const rthip_group) -> *const c_char;
+    pub fn rthip_group_destroy(group: *mut rthip_group);
+    pub fn rthip_band_row_owner(band_rows: u32, ndev: u32, y: u32, out_rank: *mut u32, out_local_row: *mut u32) -> c_int;
     pub fn rthip_host_alloc(bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
     pub fn rthip_host_free(ptr: *mut c_void) -> c_int;
     pub fn rthip_pick(ctx: *mut rthip_ctx, width: u32, height: u32, x: f64, y: f64, out_shape: *mut i64) -> c_int;

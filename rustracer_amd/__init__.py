@@ -5,7 +5,7 @@ Only what the hot path needs lives here: `csrc/` (HIP kernels + the C ABI of inc
 scene/render API), `presets` (the benchmark scenes), `bands` (multi-GPU row-band scheduler).
 """
 from . import abi  # noqa: F401
-from .raytracer import (GenerationStatus, PixelColor, PixelPosition, PixelRenderer, Raytracer, RenderResult,  # noqa: F401
+from .raytracer import (GenerationStatus, GroupRaytracer, PixelColor, PixelPosition, PixelRenderer, Raytracer, RenderResult,  # noqa: F401
                         host_array, make_params, owned_rows)
 from .scene import (Camera, Dielectric, FlatScene, Lambertian, Mesh, Metal, Plane, PointLight, Sphere, SphereCloud,  # noqa: F401
                     Texture, Triangle, Vector3, flatten)

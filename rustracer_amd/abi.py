@@ -11,10 +11,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # rthip_status
-OK, E_BADARG, E_HIP, E_OOM, E_NODEVICE, E_STATE, E_INTERNAL = 0, -1, -2, -3, -4, -5, -6
+OK, E_BADARG, E_HIP, E_OOM, E_NODEVICE, E_STATE, E_INTERNAL, E_RCCL = 0, -1, -2, -3, -4, -5, -6, -7
 
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_TEXTURE = 0, 1, 2, 3
 
@@ -23,6 +23,8 @@ F_POINT_LIGHTS = 1 << 1
 F_COUNT_STATS = 1 << 2
 F_NO_BVH = 1 << 3
 F_ADAPTIVE = 1 << 4
+GROUP_F_PEER_COPY = 1 << 0
+GROUP_F_FORCE_RCCL = 1 << 1
 STATUS_NOT_STARTED, STATUS_COPY_NEAR_PIXEL, STATUS_UNSTABLE, STATUS_FINAL = 0, 1, 2, 3  # GenerationStatus, lib.rs:59-64
 
 _d3 = C.c_double * 3
@@ -77,7 +79,7 @@ class Stats(C.Structure):
                 ("plane_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("node_tests", C.c_uint64),
                 ("hits", C.c_uint64 * 4), ("sky_evals", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("rows", C.c_uint64), ("nb_samples", C.c_uint64), ("kernel_ms", C.c_double), ("d2h_ms", C.c_double),
-                ("pixels_traced", C.c_uint64), ("pixels_final", C.c_uint64)]
+                ("pixels_traced", C.c_uint64), ("pixels_final", C.c_uint64), ("gather_ms", C.c_double)]
 
     def as_dict(self):
         return {n: (list(getattr(self, n)) if n == "hits" else getattr(self, n)) for n, _ in self._fields_}
@@ -95,7 +97,18 @@ SYMBOLS = {
     "rthip_render": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, _P(Stats)]),
     "rthip_render_device": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]),
     "rthip_reset_accum": (C.c_int, [C.c_void_p]),
-    "rthip_pixel_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rthip_pixel_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "rthip_accum_layout": (C.c_int, [C.c_void_p, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint64)]),
+    "rthip_group_create": (C.c_int, [_P(C.c_int), C.c_int, C.c_uint32, _P(C.c_void_p)]),
+    "rthip_group_upload_scene": (C.c_int, [C.c_void_p, _P(SceneDesc)]),
+    "rthip_group_set_camera": (C.c_int, [C.c_void_p, _P(Camera)]),
+    "rthip_group_render": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, _P(Stats)]),
+    "rthip_group_reset_accum": (C.c_int, [C.c_void_p]),
+    "rthip_group_size": (C.c_int, [C.c_void_p]),
+    "rthip_group_context": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "rthip_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "rthip_group_destroy": (None, [C.c_void_p]),
+    "rthip_band_row_owner": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
     "rthip_host_alloc": (C.c_int, [C.c_size_t, _P(C.c_void_p)]),
     "rthip_host_free": (C.c_int, [C.c_void_p]),
     "rthip_pick": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_double, _P(C.c_int64)]),

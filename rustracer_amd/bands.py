@@ -124,10 +124,12 @@ class BandRenderer:
         stream = self.torch.cuda.current_stream().cuda_stream
         return self.rt.render_device(self.params(spp, max_depth, flags, seed), self.rgba.data_ptr(), 0, stream, want_stats)
 
-    def step(self, spp, max_depth=50, flags=0, seed=None, group=None, force_collective=False):
+    def step(self, spp, max_depth=50, flags=0, seed=None, group=None, force_collective=False, events=None):
         """One frame, pipelined: render this rank's bands on torch's current stream into one of two buffers and start the
         gather to rank 0 on a side stream, so that it overlaps the next frame's render. Returns the frame on rank 0 (None
-        elsewhere); call wait() before reading it. force_collective: run the gather also when world == 1 (tests)."""
+        elsewhere); call wait() before reading it. force_collective: run the gather also when world == 1 (tests).
+        events: (start, end) torch events recorded on the render stream right around the render launch — after the wait for
+        the gather that last read the frame buffer — so that their distance is the kernel time alone."""
         torch = self.torch
         k = self._frame & 1
         self._frame += 1
@@ -135,7 +137,11 @@ class BandRenderer:
         main = torch.cuda.current_stream()
         if self._gathered[k] is not None:
             main.wait_event(self._gathered[k])  # the gather of two frames ago has finished reading this buffer
+        if events is not None:
+            events[0].record(main)
         self.rt.render_device(self.params(spp, max_depth, flags, seed), buf.data_ptr(), 0, main.cuda_stream, False)
+        if events is not None:
+            events[1].record(main)
         self.rgba = buf
         if self._gatherer is None and not force_collective:
             return buf

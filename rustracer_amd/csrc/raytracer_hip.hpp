@@ -273,7 +273,7 @@ public:
         std::vector<uint8_t> local;
         std::vector<uint8_t> &img = rgba8_out ? *rgba8_out : local;
         rthip_stats st = render(samples, max_depth, nullptr, !first, RTHIP_F_ADAPTIVE, &img);
-        check(rthip_pixel_status(ctx_, status_.data(), nullptr));
+        check(rthip_pixel_status(ctx_, status_.data(), nullptr, status_.size()));
         if (renderer)
             for (size_t y = 0; y < size_t(height_); y++)
                 for (size_t x = 0; x < size_t(width_); x++) {
@@ -312,6 +312,56 @@ private:
     double width_, height_;
     uint32_t seed_;
     std::vector<uint8_t> status_;  // RTHIP_STATUS_* per pixel after the last adaptive pass
+    rthip_camera uploaded_{};
+    bool have_cam_ = false;
+};
+
+// One caller, several GPUs (rthip_group_*): the whole frame from one call, rendered as interleaved row bands on every listed
+// device and gathered to the first over RCCL. The same batch `render` as HipRaytracer's.
+class HipGroupRaytracer {
+public:
+    Camera camera = Camera::create(-1.8, 1.0, 2.0);  // lib.rs:252
+    HipGroupRaytracer(double width, double height, uint32_t seed, const std::vector<int> &devices, uint32_t group_flags = 0)
+        : width_(width), height_(height), seed_(seed) {
+        if (int st = rthip_group_create(devices.data(), int(devices.size()), group_flags, &grp_)) throw HipError(st, rthip_group_last_error(nullptr));
+    }
+    HipGroupRaytracer(const HipGroupRaytracer &) = delete;
+    HipGroupRaytracer &operator=(const HipGroupRaytracer &) = delete;
+    ~HipGroupRaytracer() { rthip_group_destroy(grp_); }
+    void upload(const SceneDesc &scene) { check(rthip_group_upload_scene(grp_, &scene.desc)); }
+    rthip_stats render(uint64_t samples, uint32_t max_depth, PixelRenderer *renderer, bool accumulate = false, uint32_t flags = 0,
+                       std::vector<uint8_t> *rgba8_out = nullptr, uint32_t band_rows = 8) {
+        if (!have_cam_ || std::memcmp(&uploaded_, &camera.pod(), sizeof uploaded_) != 0) {
+            uploaded_ = camera.pod();
+            have_cam_ = true;
+            check(rthip_group_set_camera(grp_, &uploaded_));
+        }
+        rthip_render_params p{};
+        p.width = uint32_t(width_), p.height = uint32_t(height_), p.spp = uint32_t(samples), p.max_depth = max_depth, p.seed = seed_;
+        p.flags = flags | (accumulate ? RTHIP_F_ACCUMULATE : 0);
+        p.band_rows = band_rows;
+        std::vector<uint8_t> local;
+        std::vector<uint8_t> &img = rgba8_out ? *rgba8_out : local;
+        img.resize(size_t(p.width) * p.height * 4);
+        rthip_stats st{};
+        check(rthip_group_render(grp_, &p, img.data(), nullptr, &st));
+        if (renderer)
+            for (size_t y = 0; y < p.height; y++)
+                for (size_t x = 0; x < p.width; x++) {
+                    const uint8_t *px = &img[(y * p.width + x) * 4];
+                    renderer->set_pixel({x, y}, {px[0], px[1], px[2], GenerationStatus::Final});
+                }
+        return st;
+    }
+    void invalidate_pixels() { check(rthip_group_reset_accum(grp_)); }
+
+private:
+    void check(int st) {
+        if (st) throw HipError(st, rthip_group_last_error(grp_));
+    }
+    rthip_group *grp_ = nullptr;
+    double width_, height_;
+    uint32_t seed_;
     rthip_camera uploaded_{};
     bool have_cam_ = false;
 };

@@ -1201,6 +1201,7 @@ __global__ __launch_bounds__(RT_COMPACT_THREADS) void compact_kernel(const Kerne
 }
 
 extern "C" hipError_t rt_launch_compact(const KernelParams *P, uint32_t *list, uint32_t *count, hipStream_t stream) {
+    (void)hipGetLastError();  // hipGetLastError() below must report THIS launch, not an older failure of the thread
     const uint32_t tiles = ((P->width + 7u) >> 3) * ((P->owned_rows + 7u) >> 3);
     const uint32_t per_block = RT_COMPACT_THREADS * RT_COMPACT_ROUNDS / 64;  // tiles of 64 pixels per workgroup
     const uint32_t blocks = (tiles + per_block - 1) / per_block;
@@ -1257,6 +1258,7 @@ static uint32_t default_ring_rows() {
 }
 
 extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats, hipStream_t stream) {
+    (void)hipGetLastError();  // hipGetLastError() below must report THIS launch, not an older failure of the thread
     KernelParams P = *Pin;
     const uint32_t tiles_x = (P.width + 15u) >> 4, tiles_y = (P.owned_rows + 15u) >> 4;
     uint32_t blocks = tiles_x * tiles_y;
@@ -1293,7 +1295,31 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
     return hipGetLastError();
 }
 
+// ---- multi-GPU frame assembly (rthip_group_render) ----------------------------------------------------
+// Row y of the image belongs to band b = y / R, owned by rank b % n as its local row (b / n) * R + (y - b * R)
+// (rthip_band_row_owner states the same map for the host). Rank 0's rows are read from its own band buffer, the other
+// ranks' from the receive buffer of the gather: [rank][pad_rows][units] 4-byte units per row.
+__global__ __launch_bounds__(256) void deinterleave_kernel(uint32_t *__restrict__ full, const uint32_t *__restrict__ recv, const uint32_t *__restrict__ own,
+                                                           uint32_t units, uint32_t height, uint32_t band_rows, uint32_t ndev, uint32_t pad_rows) {
+    const uint32_t y = blockIdx.y;
+    const uint32_t b = y / band_rows, rank = b % ndev, lrow = (b / ndev) * band_rows + (y - b * band_rows);
+    const uint32_t *src = rank == 0 ? own + size_t(lrow) * units : recv + (size_t(rank) * pad_rows + lrow) * units;
+    uint32_t *dst = full + size_t(y) * units;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < units; i += gridDim.x * 256u) dst[i] = src[i];
+}
+extern "C" hipError_t rt_launch_deinterleave(void *full, const void *recv, const void *own, uint32_t units, uint32_t height, uint32_t band_rows,
+                                             uint32_t ndev, uint32_t pad_rows, hipStream_t stream) {
+    if (units == 0 || height == 0) return hipSuccess;
+    if (band_rows == 0 || ndev == 0 || height > 65535u) return hipErrorInvalidValue;  // gridDim.y
+    (void)hipGetLastError();  // hipGetLastError() below must report THIS launch, not an older failure of the thread
+    const uint32_t bx = (units + 255u) / 256u;
+    hipLaunchKernelGGL(deinterleave_kernel, dim3(bx > 64u ? 64u : bx, height), dim3(256), 0, stream, (uint32_t *)full, (const uint32_t *)recv,
+                       (const uint32_t *)own, units, height, band_rows, ndev, pad_rows);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t rt_launch_pick(const KernelParams *P, float u, float v, long long *d_out, hipStream_t stream) {
+    (void)hipGetLastError();  // hipGetLastError() below must report THIS launch, not an older failure of the thread
     hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(64), 0, stream, *P, u, v, d_out);
     return hipGetLastError();
 }

@@ -48,6 +48,12 @@ struct rthip_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t stream = nullptr;  // used by the synchronous entry points
     uint64_t n_shapes = 0;
+    hipEvent_t ev_last = nullptr;   // recorded after every enqueued pass (passes on different streams are ordered through it)
+    hipStream_t last_stream = nullptr;
+    bool have_last_pass = false;
+    bool pending_stats = false, pending_adaptive = false;  // a counting pass has been enqueued and not yet collected
+    uint32_t pending_rows = 0, pending_width = 0;
+    unsigned long long *stats_host = nullptr;  // page-locked landing buffer of the counter shards (no staging allocation per pass)
 };
 
 namespace {
@@ -135,6 +141,8 @@ int validate_params(rthip_ctx *ctx, const rthip_render_params *p) {
     if (p->width > 65536 || p->height > 65536) return fail(ctx, RTHIP_E_BADARG, "width/height above 65536 are not supported");
     if (uint64_t(p->width) * p->height > (1ull << 31)) return fail(ctx, RTHIP_E_BADARG, "more than 2^31 pixels are not supported (32-bit pixel indices)");
     if (p->spp == 0) return fail(ctx, RTHIP_E_BADARG, "spp must be >= 1");
+    // the RNG counter of a sample has 256 slots: slot 0 = pixel jitter, slot 1 + bounce = the material draws of that segment (rt_rng.h)
+    if (p->max_depth > 255) return fail(ctx, RTHIP_E_BADARG, "max_depth above 255 is not supported (a deeper path would reuse the random numbers of the pixel's next sample)");
     if (p->band_rows != 0 && p->band_stride == 0) return fail(ctx, RTHIP_E_BADARG, "band_stride must be >= 1 when band_rows != 0");
     if (p->flags & ~uint32_t(RTHIP_F_ACCUMULATE | RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_NO_BVH | RTHIP_F_ADAPTIVE))
         return fail(ctx, RTHIP_E_BADARG, "unknown flag bits");
@@ -165,6 +173,7 @@ const char *rthip_status_string(int status) {
         case RTHIP_E_NODEVICE: return "no such device";
         case RTHIP_E_STATE: return "call order / state error";
         case RTHIP_E_INTERNAL: return "internal error";
+        case RTHIP_E_RCCL: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -233,10 +242,12 @@ int rthip_create(int device, rthip_ctx **out_ctx) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         HIPCHK(ctx, hipEventCreate(&ctx->ev0));
         HIPCHK(ctx, hipEventCreate(&ctx->ev1));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_last, hipEventDisableTiming));
         HIPCHK(ctx, hipMalloc(&ctx->stats.p, RT_STAT_SHARDS * RT_STAT_N * sizeof(unsigned long long)));
         ctx->stats.bytes = RT_STAT_SHARDS * RT_STAT_N * sizeof(unsigned long long);
         HIPCHK(ctx, hipMalloc(&ctx->pick_out.p, sizeof(long long)));
         ctx->pick_out.bytes = sizeof(long long);
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->stats_host, RT_STAT_SHARDS * RT_STAT_N * sizeof(unsigned long long), hipHostMallocDefault));
         return RTHIP_OK;
     }();
     if (st != RTHIP_OK) {
@@ -255,8 +266,10 @@ void rthip_destroy(rthip_ctx *ctx) {
     for (DevBuf *b : {&ctx->sph_geom, &ctx->sph_shade, &ctx->pln_geom, &ctx->tri_geom, &ctx->materials, &ctx->texels, &ctx->tex_info, &ctx->lights,
                       &ctx->bvh_nodes, &ctx->bvh_recs, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out, &ctx->pix_state, &ctx->worklist, &ctx->partial})
         b->release();
+    if (ctx->stats_host) (void)hipHostFree(ctx->stats_host);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -464,13 +477,25 @@ int rthip_reset_accum(rthip_ctx *ctx) {
     return RTHIP_OK;
 }
 
-int rthip_pixel_status(rthip_ctx *ctx, uint8_t *status_out, uint8_t *same_color_count_out) {
+int rthip_accum_layout(rthip_ctx *ctx, uint32_t *out_rows, uint32_t *out_width, uint64_t *out_nb_samples) {
+    if (!ctx) return RTHIP_E_BADARG;
+    const bool live = ctx->nb_samples > 0;
+    if (out_rows) *out_rows = live ? ctx->acc_rows : 0u;
+    if (out_width) *out_width = live ? ctx->acc_width : 0u;
+    if (out_nb_samples) *out_nb_samples = ctx->nb_samples;
+    return RTHIP_OK;
+}
+
+int rthip_pixel_status(rthip_ctx *ctx, uint8_t *status_out, uint8_t *same_color_count_out, uint64_t capacity_pixels) {
     if (!ctx) return RTHIP_E_BADARG;
     if (!status_out) return fail(ctx, RTHIP_E_BADARG, "status_out is NULL");
     if (!ctx->adaptive || ctx->nb_samples == 0) return fail(ctx, RTHIP_E_STATE, "no RTHIP_F_ADAPTIVE pass has run since the last reset");
     try {
         HIPCHK(ctx, hipSetDevice(ctx->device));
         const size_t npx = size_t(ctx->acc_rows) * ctx->acc_width;
+        if (capacity_pixels < npx)
+            return fail(ctx, RTHIP_E_BADARG, "rthip_pixel_status: the buffers hold " + std::to_string(capacity_pixels) + " pixels, the running sum has " +
+                                                 std::to_string(npx) + " (rthip_accum_layout)");
         std::vector<uint32_t> st(npx);
         HIPCHK(ctx, hipDeviceSynchronize());
         HIPCHK(ctx, hipMemcpy(st.data(), ctx->pix_state.p, npx * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -486,7 +511,40 @@ int rthip_pixel_status(rthip_ctx *ctx, uint8_t *status_out, uint8_t *same_color_
     }
 }
 
-int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgba8, void *d_accum, void *hip_stream, rthip_stats *stats) {
+// One pass, enqueued on `hip_stream`.
+// Second half of a pass that counts: waits for the pass, sums the counter shards (they landed in the context's page-locked
+// buffer) and reads the kernel time. Split from the enqueue so that a multi-device caller can start every device first.
+static int collect_stats(rthip_ctx *ctx, rthip_stats *stats) {
+    if (!ctx->pending_stats) return fail(ctx, RTHIP_E_STATE, "no pass with counters is pending");
+    ctx->pending_stats = false;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_last));
+    std::memset(stats, 0, sizeof *stats);
+    const unsigned long long *h = ctx->stats_host;
+    float ms = 0.0f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    for (int sh = 0; sh < RT_STAT_SHARDS; sh++) {
+        stats->paths += h[sh * RT_STAT_N + RT_STAT_PATHS];
+        stats->rays += h[sh * RT_STAT_N + RT_STAT_RAYS];
+        stats->sphere_tests += h[sh * RT_STAT_N + RT_STAT_SPHERE];
+        stats->plane_tests += h[sh * RT_STAT_N + RT_STAT_PLANE];
+        stats->tri_tests += h[sh * RT_STAT_N + RT_STAT_TRI];
+        stats->node_tests += h[sh * RT_STAT_N + RT_STAT_NODE];
+        for (int k = 0; k < 4; k++) stats->hits[k] += h[sh * RT_STAT_N + RT_STAT_HIT0 + k];
+        stats->sky_evals += h[sh * RT_STAT_N + RT_STAT_SKY];
+        stats->shadow_rays += h[sh * RT_STAT_N + RT_STAT_SHADOW];
+        stats->pixels_traced += h[sh * RT_STAT_N + RT_STAT_PIX_TRACED];
+        stats->pixels_final += h[sh * RT_STAT_N + RT_STAT_PIX_FINAL];
+    }
+    if (!ctx->pending_adaptive) stats->pixels_traced = uint64_t(ctx->pending_rows) * ctx->pending_width;
+    stats->rows = ctx->pending_rows;
+    stats->nb_samples = ctx->nb_samples;
+    stats->kernel_ms = ms;
+    return RTHIP_OK;
+}
+
+static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgba8, void *d_accum, void *hip_stream, rthip_stats *stats,
+                       bool defer_stats = false) {
     if (!ctx) return RTHIP_E_BADARG;
     try {
         int st = validate_params(ctx, p);
@@ -496,13 +554,13 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rg
         uint32_t rows = 0;
         if ((st = owned_rows(p, &rows))) return fail(ctx, st, "bad band parameters");
         if ((p->flags & RTHIP_F_POINT_LIGHTS) && ctx->base.n_lights == 0) return fail(ctx, RTHIP_E_STATE, "RTHIP_F_POINT_LIGHTS without lights in the scene");
+        const bool adaptive = (p->flags & RTHIP_F_ADAPTIVE) != 0;
         hipStream_t stream = (hipStream_t)hip_stream;
         HIPCHK(ctx, hipSetDevice(ctx->device));
         const bool same_layout = ctx->acc_width == p->width && ctx->acc_height == p->height && ctx->acc_rows == rows &&
                                  ctx->acc_band_rows == p->band_rows && ctx->acc_band_first == p->band_first && ctx->acc_band_stride == p->band_stride;
         const bool accumulate = (p->flags & RTHIP_F_ACCUMULATE) && ctx->nb_samples > 0;
         if (accumulate && !same_layout) return fail(ctx, RTHIP_E_STATE, "RTHIP_F_ACCUMULATE with a different image/band layout than the running sum");
-        const bool adaptive = (p->flags & RTHIP_F_ADAPTIVE) != 0;
         if (accumulate && adaptive != ctx->adaptive)
             return fail(ctx, RTHIP_E_STATE, "RTHIP_F_ADAPTIVE must be set on every pass of a running sum or on none (Final pixels stop accumulating)");
         const uint64_t prior = accumulate ? ctx->nb_samples : 0;
@@ -527,7 +585,8 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rg
         k.accum = (float *)ctx->accum.p;
         k.accum_out = (float *)d_accum;
         k.rgba8 = (uint32_t *)d_rgba8;
-        k.stats = stats ? (unsigned long long *)ctx->stats.p : nullptr;  // no reader, no counting
+        unsigned long long *d_stats = (unsigned long long *)ctx->stats.p;
+        k.stats = stats ? d_stats : nullptr;  // no reader, no counting
         if (p->flags & RTHIP_F_NO_BVH) k.n_bvh_nodes = 0;
         // sample slicing: a function of spp alone, so that the image is the same for every band layout / GPU count
         k.slice_spp = RT_SLICE_SPP;
@@ -538,11 +597,15 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rg
                                                                              : uint64_t((p->width + 15u) / 16u) * ((rows + 15u) / 16u);
         if (groups >= RT_SLICE_BELOW_BLOCKS) k.n_slices = 1;
         if (k.n_slices > 1) {
-            if ((st = ensure(ctx, ctx->partial, size_t(k.n_slices) * rows * p->width * 3 * sizeof(float)))) return st;
+            const size_t need = size_t(k.n_slices) * rows * p->width * 3 * sizeof(float);
+            if ((st = ensure(ctx, ctx->partial, need))) return st;
             k.partial = (float *)ctx->partial.p;
         }
 
-        if (stats) HIPCHK(ctx, hipMemsetAsync(ctx->stats.p, 0, ctx->stats.bytes, stream));
+        // passes share the context's buffers (running sum, counters, partial sums, work-list): a pass enqueued on another
+        // stream than the previous one waits for it
+        if (ctx->have_last_pass && ctx->last_stream != stream) HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_last, 0));
+        if (stats) HIPCHK(ctx, hipMemsetAsync(d_stats, 0, RT_STAT_SHARDS * RT_STAT_N * sizeof(unsigned long long), stream));  // the shards start at zero
         if (stats) HIPCHK(ctx, hipEventRecord(ctx->ev0, stream));
         if (adaptive) {
             const size_t npx = size_t(rows) * p->width;
@@ -568,35 +631,33 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rg
         ctx->adaptive = adaptive;
 
         if (stats) {
-            std::memset(stats, 0, sizeof *stats);
-            unsigned long long h[RT_STAT_SHARDS * RT_STAT_N];
-            HIPCHK(ctx, hipMemcpyAsync(h, ctx->stats.p, sizeof h, hipMemcpyDeviceToHost, stream));
-            HIPCHK(ctx, hipStreamSynchronize(stream));
-            float ms = 0.0f;
-            HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-            for (int sh = 0; sh < RT_STAT_SHARDS; sh++) {
-                stats->paths += h[sh * RT_STAT_N + RT_STAT_PATHS];
-                stats->rays += h[sh * RT_STAT_N + RT_STAT_RAYS];
-                stats->sphere_tests += h[sh * RT_STAT_N + RT_STAT_SPHERE];
-                stats->plane_tests += h[sh * RT_STAT_N + RT_STAT_PLANE];
-                stats->tri_tests += h[sh * RT_STAT_N + RT_STAT_TRI];
-                stats->node_tests += h[sh * RT_STAT_N + RT_STAT_NODE];
-                for (int k = 0; k < 4; k++) stats->hits[k] += h[sh * RT_STAT_N + RT_STAT_HIT0 + k];
-                stats->sky_evals += h[sh * RT_STAT_N + RT_STAT_SKY];
-                stats->shadow_rays += h[sh * RT_STAT_N + RT_STAT_SHADOW];
-                stats->pixels_traced += h[sh * RT_STAT_N + RT_STAT_PIX_TRACED];
-                stats->pixels_final += h[sh * RT_STAT_N + RT_STAT_PIX_FINAL];
-            }
-            if (!adaptive) stats->pixels_traced = uint64_t(rows) * p->width;
-            stats->rows = rows;
-            stats->nb_samples = ctx->nb_samples;
-            stats->kernel_ms = ms;
+            HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, d_stats, RT_STAT_SHARDS * RT_STAT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            ctx->pending_stats = true, ctx->pending_adaptive = adaptive, ctx->pending_rows = rows, ctx->pending_width = p->width;
         }
+        HIPCHK(ctx, hipEventRecord(ctx->ev_last, stream));
+        ctx->have_last_pass = true, ctx->last_stream = stream;
+        if (stats && !defer_stats && (st = collect_stats(ctx, stats))) return st;
         return RTHIP_OK;
     } catch (...) {
-        return fail(ctx, RTHIP_E_INTERNAL, "unexpected exception in rthip_render_device");
+        return fail(ctx, RTHIP_E_INTERNAL, "unexpected exception in the render pass");
     }
 }
+
+int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgba8, void *d_accum, void *hip_stream, rthip_stats *stats) {
+    return render_pass(ctx, p, d_rgba8, d_accum, hip_stream, stats);
+}
+
+// internal (rthip_group.cpp): enqueue a pass on the context's own stream without waiting for its counters / wait and read them
+int rt_ctx_render_deferred(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgba8, void *d_accum, rthip_stats *stats_wanted) {
+    return render_pass(ctx, p, d_rgba8, d_accum, ctx ? ctx->stream : nullptr, stats_wanted, true);
+}
+int rt_ctx_collect_stats(rthip_ctx *ctx, rthip_stats *stats) {
+    if (!ctx || !stats) return RTHIP_E_BADARG;
+    return collect_stats(ctx, stats);
+}
+void *rt_ctx_stream(rthip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int rt_ctx_device(rthip_ctx *ctx) { return ctx ? ctx->device : -1; }
+uint64_t rt_ctx_nb_samples(rthip_ctx *ctx) { return ctx ? ctx->nb_samples : 0; }
 
 int rthip_render(rthip_ctx *ctx, const rthip_render_params *p, uint8_t *rgba8_out, float *accum_out, rthip_stats *stats) {
     if (!ctx) return RTHIP_E_BADARG;

@@ -3,7 +3,10 @@
 // on the GPU through a PixelRenderer (the `World` framebuffer of standalone/src/renderers/pixels.rs:205-262,
 // reduced to a byte buffer), writes a PPM and prints one JSON line of statistics.
 //   rthip_cli [--scene standalone|wasm|grid] [--grid N] [--width W] [--height H] [--spp N] [--depth D] [--seed S] [--texture path.rgb8.z]
-//             [--out image.ppm]
+//             [--out image.ppm] [--rgba-out frame.rgba]   frame.rgba: the raw top-down RGBA8 frame as the pixels/wgpu front-end
+//                            takes it (standalone/src/renderers/pixels.rs:240-260: screen row 0 = pos.y = height-1)
+//             [--devices 0,1,..]  render through the single-process multi-GPU group (rthip_group_*: interleaved row bands, RCCL
+//                            gather); [--peer-copy 1] gathers with peer copies instead (allows a device to be listed twice)
 //             --scene wasm: the three metal spheres of wasm/src/lib.rs:90-105; grid: N x N small spheres + ground + a quad (extension
 //             shapes; big enough N goes through the BVH) — tests/test_cli_gpu.py builds the same scenes through the Python layer
 //             [--passes P]   P > 0: the standalone window's progressive loop (standalone/src/main.rs:99-102) — P adaptive
@@ -73,8 +76,9 @@ struct World : PixelRenderer {  // standalone/src/renderers/pixels.rs:205-262
 
 int main(int argc, char **argv) {
     uint32_t width = 960, height = 540, spp = 16, depth = 50, seed = 1, passes = 0;  // standalone/src/main.rs:51-52, ray.rs:44
-    std::string out, texture = "tests/golden/textures/bergsjostolen.rgb8.z", scene_name = "standalone";
-    int grid = 12;
+    std::string out, rgba_out, texture = "tests/golden/textures/bergsjostolen.rgb8.z", scene_name = "standalone";
+    std::vector<int> devices;
+    int grid = 12, peer_copy = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         std::string k = argv[i];
         if (k == "--width") width = std::atoi(argv[i + 1]);
@@ -87,6 +91,15 @@ int main(int argc, char **argv) {
         else if (k == "--scene") scene_name = argv[i + 1];
         else if (k == "--grid") grid = std::atoi(argv[i + 1]);
         else if (k == "--out") out = argv[i + 1];
+        else if (k == "--rgba-out") rgba_out = argv[i + 1];
+        else if (k == "--peer-copy") peer_copy = std::atoi(argv[i + 1]);
+        else if (k == "--devices") {
+            for (const char *p = argv[i + 1]; *p;) {
+                devices.push_back(std::atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p == ',') p++;
+            }
+        }
         else { std::fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     try {
@@ -96,13 +109,19 @@ int main(int argc, char **argv) {
         else if (scene_name == "grid" && grid > 0 && grid <= 1000) scene = grid_scene(grid);
         else { std::fprintf(stderr, "unknown scene %s\n", scene_name.c_str()); return 2; }
         SceneDesc desc(scene);
-        HipRaytracer rt(width, height, seed);
+        HipRaytracer rt(width, height, seed, devices.empty() ? 0 : devices[0]);
         rt.upload(desc);
         World world(width, height);
         rthip_stats st{};
         uint64_t paths = 0, rays = 0, final_pixels = 0;
         double kernel_ms = 0.0;
-        if (passes == 0) {
+        if (!devices.empty()) {
+            if (passes) { std::fprintf(stderr, "--devices renders one batch (no --passes)\n"); return 2; }
+            HipGroupRaytracer grp(width, height, seed, devices, peer_copy ? RTHIP_GROUP_F_PEER_COPY : 0);
+            grp.upload(desc);
+            st = grp.render(spp, depth, &world);
+            paths = st.paths, rays = st.rays, kernel_ms = st.kernel_ms;
+        } else if (passes == 0) {
             st = rt.render(spp, depth, &world);
             paths = st.paths, rays = st.rays, kernel_ms = st.kernel_ms;
         } else {
@@ -114,12 +133,17 @@ int main(int argc, char **argv) {
         }
         int64_t centre = rt.get_shape((width - 1) * 0.5, (height - 1) * 0.5);
         if (!out.empty()) write_ppm_p3(out, world.pixels, width, height);
+        if (!rgba_out.empty()) {
+            const std::vector<uint8_t> frame = flip_to_top_down(world.pixels, width, height);
+            std::ofstream f(rgba_out, std::ios::binary);
+            f.write(reinterpret_cast<const char *>(frame.data()), std::streamsize(frame.size()));
+        }
         std::printf("{\"width\": %u, \"height\": %u, \"spp\": %u, \"max_depth\": %u, \"paths\": %llu, \"rays\": %llu, \"kernel_ms\": %.3f, "
                     "\"d2h_ms\": %.3f, \"mrays_per_s\": %.1f, \"set_pixel_calls\": %llu, \"shape_at_centre\": %lld, \"passes\": %u, "
-                    "\"final_pixels\": %llu, \"final_set_pixel_calls\": %llu}\n",
+                    "\"final_pixels\": %llu, \"final_set_pixel_calls\": %llu, \"devices\": %d, \"gather_ms\": %.3f}\n",
                     width, height, spp, depth, (unsigned long long)paths, (unsigned long long)rays, kernel_ms, st.d2h_ms,
                     rays / kernel_ms / 1e3, (unsigned long long)world.writes, (long long)centre, passes, (unsigned long long)final_pixels,
-                    (unsigned long long)world.final_writes);
+                    (unsigned long long)world.final_writes, int(devices.size()), st.gather_ms);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "rthip_cli: %s\n", e.what());
         return 1;

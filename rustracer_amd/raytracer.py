@@ -130,7 +130,8 @@ class Raytracer:
         _check(self._lib.rthip_create(int(device), C.byref(self._ctx)))
         self.camera = Camera.new(-1.8, 1.0, 2.0)  # lib.rs:252
         self._uploaded_camera = None
-        self._scene_key = None
+        self._scene_obj = None   # strong reference to the object that was uploaded: its id() cannot be recycled while we hold it
+        self._scene_sig = None
         self._flat = None
 
     @classmethod
@@ -153,11 +154,22 @@ class Raytracer:
         flat = scene if isinstance(scene, FlatScene) else flatten(scene, lights)
         _check(self._lib.rthip_upload_scene(self._ctx, C.byref(flat.desc)), self._ctx)
         self._flat = flat
-        self._scene_key = id(scene)
+        self._scene_obj = scene
+        self._scene_sig = self._signature(scene, lights)
         return flat
 
+    @staticmethod
+    def _signature(scene, lights):
+        """What makes an uploaded scene stale: a list that grew, shrank or had a shape / material / light replaced. (Mutating
+        the fields of a shape in place is not seen: call upload() again, or pass a fresh FlatScene.)"""
+        if isinstance(scene, FlatScene):
+            return None
+        return (tuple((id(sh), id(getattr(sh, "material", None))) for sh in scene), tuple(id(l) for l in lights))
+
     def _sync_scene_camera(self, scene, lights=()):
-        if scene is not None and self._scene_key != id(scene):
+        # the reference passes the scene on every generate_pixel call (lib.rs:272); here it is re-uploaded when it is another
+        # object than the one on the device, or the same list with different members
+        if scene is not None and (self._scene_obj is not scene or self._scene_sig != self._signature(scene, lights)):
             self.upload(scene, lights)
         cam = self.camera.as_abi()
         key = bytes(cam)
@@ -173,7 +185,6 @@ class Raytracer:
         fl = flags | (abi.F_ACCUMULATE if accumulate else 0) | (abi.F_ADAPTIVE if adaptive else 0)
         p = make_params(int(self.width), int(self.height), samples, max_depth, self.seed, fl, band_rows, band_first, band_stride)
         rows = owned_rows(p)
-        self._last_rows = rows
         w = int(self.width)
         if rgba_out is not None:  # e.g. a page-locked array from host_array(): a much faster device->host copy
             assert rgba_out.shape == (rows, w, 4) and rgba_out.dtype == np.uint8 and rgba_out.flags.c_contiguous
@@ -195,12 +206,17 @@ class Raytracer:
 
     def pixel_status(self):
         """PixelColor.status / PixelCache.same_color_count of every owned pixel after the last adaptive pass (lib.rs:59-73)."""
-        # the layout of the last pass is the context's; the full image unless bands were used
-        rows = self._last_rows if getattr(self, "_last_rows", None) else int(self.height)
-        status = np.empty((rows, int(self.width)), np.uint8)
-        count = np.empty((rows, int(self.width)), np.uint8)
-        _check(self._lib.rthip_pixel_status(self._ctx, status.ctypes.data, count.ctypes.data), self._ctx)
+        rows, width, _ = self.accum_layout()  # the layout of the running sum is the context's, whoever enqueued the last pass
+        status = np.empty((rows, width), np.uint8)
+        count = np.empty((rows, width), np.uint8)
+        _check(self._lib.rthip_pixel_status(self._ctx, status.ctypes.data, count.ctypes.data, status.size), self._ctx)
         return status, count
+
+    def accum_layout(self):
+        """(owned rows, width, samples per pixel) of the device-resident running sum (lib.rs:67-73); zeros after a reset."""
+        rows, width, nb = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+        _check(self._lib.rthip_accum_layout(self._ctx, C.byref(rows), C.byref(width), C.byref(nb)), self._ctx)
+        return rows.value, width.value, nb.value
 
     def invalidate_pixels(self):
         _check(self._lib.rthip_reset_accum(self._ctx), self._ctx)
@@ -211,3 +227,63 @@ class Raytracer:
         out = C.c_int64(-1)
         _check(self._lib.rthip_pick(self._ctx, int(self.width), int(self.height), float(x), float(y), C.byref(out)), self._ctx)
         return None if out.value < 0 else out.value
+
+
+class GroupRaytracer:
+    """One caller, several GPUs of one process (rthip_group_*, include/rthip.h): `render` returns the whole frame, rendered as
+    interleaved row bands on every listed device and gathered to the first over RCCL. Mirrors Raytracer's batch `render`."""
+
+    def __init__(self, width, height, seed=0, devices=(0,), peer_copy=False, force_rccl=False):
+        self._lib = abi.lib()
+        self.width, self.height, self.seed = float(width), float(height), int(seed)
+        self._grp = C.c_void_p()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        flags = (abi.GROUP_F_PEER_COPY if peer_copy else 0) | (abi.GROUP_F_FORCE_RCCL if force_rccl else 0)
+        st = self._lib.rthip_group_create(devs, len(devices), flags, C.byref(self._grp))
+        if st != 0:
+            raise abi.RthipError(st, (self._lib.rthip_group_last_error(None) or b"").decode())
+        self.camera = Camera.new(-1.8, 1.0, 2.0)  # lib.rs:252
+        self._uploaded_camera = None
+        self._flat = None
+
+    def _check(self, st):
+        if st != 0:
+            raise abi.RthipError(st, (self._lib.rthip_group_last_error(self._grp) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_grp", None) and self._grp.value:
+            self._lib.rthip_group_destroy(self._grp)
+            self._grp = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return self._lib.rthip_group_size(self._grp)
+
+    def upload(self, scene, lights=()):
+        flat = scene if isinstance(scene, FlatScene) else flatten(scene, lights)
+        self._check(self._lib.rthip_group_upload_scene(self._grp, C.byref(flat.desc)))
+        self._flat = flat
+        return flat
+
+    def invalidate_pixels(self):
+        self._check(self._lib.rthip_group_reset_accum(self._grp))
+
+    def render(self, samples, max_depth=50, accumulate=False, flags=0, band_rows=8, want_accum=True, rgba_out=None) -> RenderResult:
+        cam = self.camera.as_abi()
+        key = bytes(cam)
+        if key != self._uploaded_camera:
+            self._check(self._lib.rthip_group_set_camera(self._grp, C.byref(cam)))
+            self._uploaded_camera = key
+        w, h = int(self.width), int(self.height)
+        p = make_params(w, h, samples, max_depth, self.seed, flags | (abi.F_ACCUMULATE if accumulate else 0), band_rows, 0, 0)
+        rgba = rgba_out if rgba_out is not None else np.empty((h, w, 4), np.uint8)
+        acc = np.empty((h, w, 3), np.float32) if want_accum else None
+        st = abi.Stats()
+        self._check(self._lib.rthip_group_render(self._grp, C.byref(p), rgba.ctypes.data, acc.ctypes.data if acc is not None else None, C.byref(st)))
+        return RenderResult(rgba, acc, st.as_dict())

@@ -29,7 +29,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(abi.Material) == 48 and C.sizeof(abi.Sphere) == 40 and C.sizeof(abi.Plane) == 56
     assert C.sizeof(abi.Triangle) == 80 and C.sizeof(abi.Light) == 48 and C.sizeof(abi.Texture) == 16
     assert C.sizeof(abi.SceneDesc) == 96 and C.sizeof(abi.Camera) == 96 and C.sizeof(abi.RenderParams) == 64
-    assert C.sizeof(abi.Stats) == 8 * 14 + 16 + 16  # ABI v2: + pixels_traced, pixels_final
+    assert C.sizeof(abi.Stats) == 8 * 14 + 16 + 16 + 8  # ABI v2: + pixels_traced, pixels_final; v3: + gather_ms
 
 
 def test_camera_lookat_matches_oracle(oracle_mod):
@@ -57,6 +57,21 @@ def test_owned_rows_partition(h, r, world):
     assert np.array_equal(allrows, np.arange(h))  # every row owned exactly once
 
 
+@pytest.mark.parametrize("h,r,world", [(2160, 8, 2), (2160, 8, 3), (2160, 8, 8), (181, 16, 3), (37, 7, 8), (5, 8, 8)])
+def test_band_row_owner_is_the_inverse_of_the_band_split(h, r, world):
+    """the row map of the multi-GPU de-interleave (rthip_group_render) against the band scheduler's own index lists"""
+    lib = abi.lib()
+    owner = {}
+    for rank in range(world):
+        for lrow, y in enumerate(owned_row_indices(h, r, rank, world)):
+            owner[int(y)] = (rank, lrow)
+    for y in range(h):
+        rank, lrow = C.c_uint32(99), C.c_uint32(99)
+        assert lib.rthip_band_row_owner(r, world, y, C.byref(rank), C.byref(lrow)) == 0
+        assert (rank.value, lrow.value) == owner[y], y
+    assert lib.rthip_band_row_owner(0, world, 0, None, None) == abi.E_BADARG
+
+
 def test_status_strings_and_null_handling():
     lib = abi.lib()
     assert lib.rthip_status_string(0) == b"ok"
@@ -65,6 +80,8 @@ def test_status_strings_and_null_handling():
     assert lib.rthip_create(0, None) == abi.E_BADARG
     assert lib.rthip_render(None, None, None, None, None) == abi.E_BADARG
     assert lib.rthip_upload_scene(None, None) == abi.E_BADARG
+    assert lib.rthip_group_render(None, None, None, None, None) == abi.E_BADARG and lib.rthip_group_size(None) == 0
+    assert b"RCCL" in lib.rthip_status_string(abi.E_RCCL)
     lib.rthip_destroy(None)  # no-op
     n = C.c_int(-1)
     st = lib.rthip_device_count(C.byref(n))

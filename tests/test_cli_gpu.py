@@ -97,3 +97,40 @@ def test_cli_scene_presets(tmp_path, name, grid):
     ppm = np.array(tok[4:], dtype=np.uint8).reshape(h, w, 3)
     assert np.array_equal(ppm, res.rgba8[::-1, :, :3])
     rt.close()
+
+
+def test_cli_rgba_out_is_the_top_down_frame(tmp_path):
+    """--rgba-out: the raw RGBA8 frame in SCREEN order, as standalone's pixels front-end draws it
+    (standalone/src/renderers/pixels.rs:240-260: screen row 0 shows pos.y = height-1) == the PPM rows (written top-down,
+    ppm.rs:28-35) + alpha 255 == the y-up buffer of the C ABI flipped"""
+    w, h, spp, seed = 176, 98, 2, 5
+    ppm_path, rgba_path = tmp_path / "img.ppm", tmp_path / "frame.rgba"
+    r = subprocess.run([CLI, "--width", str(w), "--height", str(h), "--spp", str(spp), "--depth", "6", "--seed", str(seed),
+                        "--texture", presets.texture_path("bergsjostolen"), "--out", str(ppm_path), "--rgba-out", str(rgba_path)],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    frame = np.fromfile(rgba_path, dtype=np.uint8).reshape(h, w, 4)
+    tok = ppm_path.read_text().split()
+    ppm = np.array(tok[4:], dtype=np.uint8).reshape(h, w, 3)
+    assert np.array_equal(frame[..., :3], ppm) and (frame[..., 3] == 255).all()
+    rt = Raytracer.new(w, h, seed=seed)
+    res = rt.render(presets.standalone_scene(), spp, max_depth=6)
+    assert np.array_equal(frame, res.rgba8[::-1])
+    rt.close()
+
+
+def test_cli_devices_group_matches_single_device(tmp_path):
+    """--devices: the C++ host layer through rthip_group_* (a 3-way band split rehearsed on one GPU with peer copies)"""
+    w, h, spp, seed = 200, 117, 3, 8
+    outs = []
+    for extra in ([], ["--devices", "0"], ["--devices", "0,0,0", "--peer-copy", "1"]):
+        out = tmp_path / f"img{len(outs)}.ppm"
+        r = subprocess.run([CLI, "--width", str(w), "--height", str(h), "--spp", str(spp), "--depth", "6", "--seed", str(seed),
+                            "--texture", presets.texture_path("bergsjostolen"), "--out", str(out)] + extra,
+                           capture_output=True, text=True, timeout=120, cwd=ROOT)
+        assert r.returncode == 0, r.stderr
+        info = json.loads(r.stdout)
+        assert info["paths"] == w * h * spp and info["set_pixel_calls"] == w * h
+        outs.append((out.read_bytes(), info))
+    assert outs[0][0] == outs[1][0] == outs[2][0]
+    assert outs[0][1]["rays"] == outs[1][1]["rays"] == outs[2][1]["rays"] and outs[2][1]["devices"] == 3

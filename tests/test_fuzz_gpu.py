@@ -2,9 +2,11 @@
 radii, overlapping spheres, planes / triangles / point lights, the camera inside a sphere, 1..300 spheres through the LDS scan,
 the BVH and the forced linear scan, odd image sizes, depths 1..50. For every scene:
   * the production kernel and the instrumented kernel (no empty-tile path, other register allocation) agree bit for bit;
-  * device vs oracle f64 meets the bar (|delta| <= 1/255 on >= 99.9 % of pixels) — or, where FP32 itself cannot (noise
-    textures seen at grazing angles, chaotic glass), the device is no worse than the SAME formulas evaluated in float on the
-    CPU (the oracle's f32 mode), which is what "FP32 arithmetic" costs on such inputs."""
+  * device vs oracle f64 meets the bar (|delta| <= 1/255 on >= 99.9 % of pixels), strictly. A scene that legitimately cannot
+    (tools/fuzz_parity.py found ~1 in 10 among 810 random scenes: noise textures on extension planes seen at grazing angles,
+    hundreds of glass spheres at depth 50 with few samples) must be NAMED in KNOWN_BELOW_BAR with its measured fractions and
+    the reason; for such a seed the test then demands the measured value (minus one pixel) and "no worse than the same
+    formulas in float on the CPU" (the oracle's f32 mode). None of the 24 seeds run here needs an entry."""
 import os
 import sys
 
@@ -19,6 +21,10 @@ from rustracer_amd import Raytracer, abi, flatten, make_params  # noqa: E402
 from rustracer_amd.scene import Camera  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+
+# seed -> (device fraction within 1/255 vs oracle f64, f32-on-CPU fraction vs f64, why) as measured on MI355X.
+# Round 2 (GPUTEST log gpurun_out/r2a): every seed of 100..123 is at or above 99.9 %, so the table is empty and the bar is strict.
+KNOWN_BELOW_BAR = {}
 
 
 @pytest.mark.parametrize("seed", list(range(100, 124)))
@@ -39,11 +45,14 @@ def test_random_scene(oracle_mod, seed):
     p = make_params(w, h, spp, depth, seed, flags)
     ref64, _, st, _ = oracle_mod.render(flat, cam, p, precision=64)
     _, ok = mismatch_histogram(plain.rgba8, ref64)
-    if ok < 0.999:
+    if seed in KNOWN_BELOW_BAR:
+        measured, _, why = KNOWN_BELOW_BAR[seed]
         ref32, _, _, _ = oracle_mod.render(flat, cam, p, precision=32)
         _, ok32 = mismatch_histogram(ref32, ref64)
-        print(f"\nseed {seed}: device {ok * 100:.3f} % vs f32-on-CPU {ok32 * 100:.3f} % ({len(flat.spheres)} spheres, flavour {flavour}, {w}x{h}@{spp} d{depth})")
-        assert ok >= ok32 - 2.0 / (w * h) - 0.002, f"device {ok} worse than the float oracle {ok32}"
+        print(f"\nseed {seed} ({why}): device {ok * 100:.3f} % vs f32-on-CPU {ok32 * 100:.3f} % ({len(flat.spheres)} spheres, flavour {flavour}, {w}x{h}@{spp} d{depth})")
+        assert ok >= measured - 1.0 / (w * h) and ok >= ok32 - 1.0 / (w * h), f"seed {seed}: device {ok}, recorded {measured}, float oracle {ok32}"
+    else:
+        assert ok >= 0.999, f"seed {seed}: device within 1/255 on {ok * 100:.3f} % of pixels ({len(flat.spheres)} spheres, flavour {flavour}, {w}x{h}@{spp} d{depth})"
     assert counted.stats["paths"] == st["paths"] and abs(counted.stats["rays"] - st["rays"]) <= 5e-3 * st["rays"] + 4
     rt.close()
 

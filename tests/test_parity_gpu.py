@@ -227,7 +227,8 @@ def test_bvh_equals_brute_force(oracle_mod, default_camera):
     hist, ok = mismatch_histogram(bvh.rgba8, ref)
     _, ok_f32cpu = mismatch_histogram(ref32, ref)
     print(f"\nbvh scene depth 2: {describe(hist2, ok2)}\nbvh scene depth 8: {describe(hist, ok)} (f32-on-CPU vs f64: {ok_f32cpu * 100:.3f} %)")
-    assert ok >= 0.995 and ok >= ok_f32cpu - 0.0005
+    # ONE named case, measured on MI355X (round 1 and 2): device 99.78 % within 1/255, f32-on-CPU 99.65 %
+    assert ok >= 0.9970 and ok >= ok_f32cpu - 0.0005
     assert abs(bvh.stats["rays"] - st["rays"]) <= 5e-3 * st["rays"]
     # picking goes through the same traversal
     rng = np.random.default_rng(1)
@@ -340,6 +341,19 @@ def test_error_behaviour():
     # a running sum holds at most 2^24 samples per pixel (the RNG counter of a sample would wrap)
     huge = make_params(64, 36, (1 << 24), flags=abi.F_ACCUMULATE)
     assert lib.rthip_render(ctx, C.byref(huge), None, None, None) == abi.E_BADARG and b"2^24" in lib.rthip_last_error(ctx)
+    # ... and a path at most 255 segments (the counter RNG has 256 slots per sample: slot 0 = jitter, 1 + bounce = materials)
+    deep = make_params(64, 36, 1, max_depth=256)
+    assert lib.rthip_render(ctx, C.byref(deep), None, None, None) == abi.E_BADARG and b"255" in lib.rthip_last_error(ctx)
+    assert lib.rthip_render(ctx, C.byref(make_params(64, 36, 1, max_depth=255)), None, None, None) == 0
+    # rthip_pixel_status: needs an adaptive running sum, and buffers that hold it
+    status = np.zeros(64 * 36, np.uint8)
+    assert lib.rthip_pixel_status(ctx, status.ctypes.data, None, status.size) == abi.E_STATE
+    ad = make_params(64, 36, 1, flags=abi.F_ADAPTIVE)
+    assert lib.rthip_render(ctx, C.byref(ad), None, None, None) == 0
+    rows, width, nb = C.c_uint32(0), C.c_uint32(0), C.c_uint64(0)
+    assert lib.rthip_accum_layout(ctx, C.byref(rows), C.byref(width), C.byref(nb)) == 0 and (rows.value, width.value, nb.value) == (36, 64, 1)
+    assert lib.rthip_pixel_status(ctx, status.ctypes.data, None, status.size - 1) == abi.E_BADARG
+    assert lib.rthip_pixel_status(ctx, status.ctypes.data, None, status.size) == 0 and (status == abi.STATUS_UNSTABLE).all()
     lib.rthip_destroy(ctx)
 
 
@@ -409,6 +423,80 @@ def test_full_size_8k_bvh_properties():
     brute = rt.render(flat, spp, max_depth=depth, flags=abi.F_NO_BVH, band_rows=8, band_first=mid, band_stride=nbands, want_accum=False)
     assert np.array_equal(brute.rgba8, whole.rgba8[mid * 8:(mid + 1) * 8])
     rt.close()
+
+
+def test_full_size_c4_million_triangles(oracle_mod, default_camera):
+    """C4 at its full size: 49 icospheres x 20 480 = 1 003 520 triangles + the ground sphere, 3840x2160, depth 50:
+    tree depth, quantised frames at that extent, the 48 MB record buffer and the leaf references of a 2^20-primitive tree.
+    (i) counter identities, determinism, 8-way band split == whole frame (checksum of checksums); (ii) BVH == the linear scan
+    of ray.rs:47-67 bit for bit on one 8-row band through the meshes; (iii) device vs the f64 oracle (which scans all
+    1 003 521 shapes per ray) on a 48x48 window over a mesh silhouette, at the bar."""
+    import zlib
+    w, h, spp, depth = 3840, 2160, 1, 50
+    flat = flatten(presets.mesh_scene())
+    assert len(flat.triangles) == 1003520 and len(flat.spheres) == 1
+    rt = Raytracer.new(w, h, seed=9)
+    whole = rt.render(flat, spp, max_depth=depth, flags=abi.F_COUNT_STATS)
+    s = whole.stats
+    assert s["paths"] == w * h * spp and s["paths"] <= s["rays"] <= s["paths"] * depth
+    assert s["node_tests"] > 0 and s["node_tests"] % 2 == 0 and s["tri_tests"] > 0 and s["sphere_tests"] > 0
+    assert sum(s["hits"]) + s["sky_evals"] >= s["rays"]
+    assert s["hits"][abi.MAT_LAMBERTIAN] > 0 and s["hits"][abi.MAT_METAL] > 0 and s["hits"][abi.MAT_DIELECTRIC] == 0
+    again = rt.render(flat, spp, max_depth=depth, want_accum=False)
+    assert zlib.crc32(again.rgba8.tobytes()) == zlib.crc32(whole.rgba8.tobytes())
+    full = np.empty_like(whole.rgba8)
+    for rank in range(8):
+        part = rt.render(flat, spp, max_depth=depth, band_rows=8, band_first=rank, band_stride=8, want_accum=False)
+        full[owned_row_indices(h, 8, rank, 8)] = part.rgba8
+    assert zlib.crc32(full.tobytes()) == zlib.crc32(whole.rgba8.tobytes())
+    # (ii) a pixel on a mesh near the image centre (picking walks the same tree); the band of 8 rows through it by brute force
+    target = None
+    for dy in range(0, 800, 16):
+        for dx in range(0, 1600, 16):
+            for sx, sy in ((1, 1), (-1, 1), (1, -1), (-1, -1)):
+                x, y = w // 2 + sx * dx, h // 2 + sy * dy
+                shape = rt.get_shape(flat, x, y)
+                if shape is not None and shape >= 1:
+                    target = (x, y)
+                    break
+            if target:
+                break
+        if target:
+            break
+    assert target, "no mesh in view"
+    band = target[1] // 8
+    brute = rt.render(flat, spp, max_depth=depth, flags=abi.F_NO_BVH | abi.F_COUNT_STATS, band_rows=8, band_first=band, band_stride=h // 8)
+    assert brute.stats["node_tests"] == 0 and brute.stats["tri_tests"] == brute.stats["rays"] * 1003520
+    assert np.array_equal(brute.rgba8, whole.rgba8[band * 8:(band + 1) * 8])
+    assert np.array_equal(brute.accum.view(np.uint32), whole.accum[band * 8:(band + 1) * 8].view(np.uint32))
+    # (iii) the oracle on a 48x48 window around that pixel (the first mesh pixel met walking outwards from the centre: a silhouette)
+    x0, y0 = min(max(target[0] - 24, 0), w - 48), min(max(target[1] - 24, 0), h - 48)
+    ref, _, st, secs = oracle_mod.render(flat, default_camera, make_params(w, h, spp, depth, 9), precision=64, crop=(x0, y0, 48, 48))
+    hist, ok = assert_parity(whole.rgba8[y0:y0 + 48, x0:x0 + 48], ref, "C4 window vs oracle f64")
+    print(f"\nC4 full size: {s['rays']} rays, {s['node_tests'] / s['rays']:.1f} node tests and {s['tri_tests'] / s['rays']:.2f} triangle tests per ray; "
+          f"window ({x0},{y0}) 48x48 vs oracle f64 ({secs:.1f} s, {st['tri_tests'] / max(1, st['rays']):.0f} tests per ray): {describe(hist, ok)}")
+    rt.close()
+
+
+def test_two_temporary_scenes_on_one_raytracer():
+    """the scene is passed on every call like generate_pixel's `scene` argument (lib.rs:272): a second temporary list (whose
+    id() CPython may well recycle from the first) and an in-place edit of a list must both reach the device"""
+    rt = Raytracer.new(160, 90, seed=3)
+    a = rt.render(presets.standalone_scene(), 2, max_depth=5)
+    b = rt.render(presets.wasm_scene(), 2, max_depth=5)
+    fresh = Raytracer.new(160, 90, seed=3)
+    want_b = fresh.render(presets.wasm_scene(), 2, max_depth=5)
+    assert np.array_equal(b.rgba8, want_b.rgba8) and not np.array_equal(a.rgba8, b.rgba8)
+    scene = presets.wasm_scene()
+    rt.render(scene, 2, max_depth=5)
+    scene.append(Sphere.new((-0.9, 0.0, -1.0), 0.4, Lambertian.new((0.9, 0.1, 0.1))))
+    c = rt.render(scene, 2, max_depth=5)
+    want_c = fresh.render(list(scene), 2, max_depth=5)
+    assert np.array_equal(c.rgba8, want_c.rgba8) and not np.array_equal(c.rgba8, want_b.rgba8)
+    scene[-1] = Sphere.new((-0.9, 0.0, -1.0), 0.4, Lambertian.new((0.1, 0.9, 0.1)))   # same length, another shape
+    d = rt.render(scene, 2, max_depth=5)
+    assert not np.array_equal(d.rgba8, c.rgba8)
+    rt.close(), fresh.close()
 
 
 def test_bvh_point_lights_and_planes(oracle_mod, default_camera):
