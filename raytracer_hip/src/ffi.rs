@@ -18,6 +18,7 @@ pub const RTHIP_STATUS_UNSTABLE: u8 = 2;
 pub const RTHIP_STATUS_FINAL: u8 = 3;
 pub const RTHIP_GROUP_F_PEER_COPY: u32 = 1 << 0;
 pub const RTHIP_GROUP_F_FORCE_RCCL: u32 = 1 << 1;
+pub const RTHIP_NOALLOC_SCRATCH_BYTES: usize = 64 << 20;
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct rthip_material { pub kind: u32, pub texture: u32, pub albedo: [f64; 3], pub param: f64, pub shininess: f64 }
@@ -71,6 +72,8 @@ extern "C" {
     pub fn rthip_render_device(ctx: *mut rthip_ctx, params: *const rthip_render_params, d_rgba8: *mut c_void, d_accum: *mut c_void,
                                hip_stream: *mut c_void, stats: *mut rthip_stats) -> c_int;
     pub fn rthip_reset_accum(ctx: *mut rthip_ctx) -> c_int;
+    pub fn rthip_render_device_noalloc(ctx: *mut rthip_ctx, params: *const rthip_render_params, d_rgba8: *mut c_void, d_accum: *mut c_void,
+                                       hip_stream: *mut c_void, stats: *mut rthip_stats) -> c_int;
     pub fn rthip_pixel_status(ctx: *mut rthip_ctx, status_out: *mut u8, same_color_count_out: *mut u8, capacity_pixels: u64) -> c_int;
     pub fn rthip_accum_layout(ctx: *mut rthip_ctx, out_rows: *mut u32, out_width: *mut u32, out_nb_samples: *mut u64) -> c_int;
     pub fn rthip_group_create(devices: *const c_int, ndev: c_int, flags: u32, out_group: *mut *mut rthip_group) -> c_int;

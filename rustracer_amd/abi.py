@@ -25,6 +25,7 @@ F_NO_BVH = 1 << 3
 F_ADAPTIVE = 1 << 4
 GROUP_F_PEER_COPY = 1 << 0
 GROUP_F_FORCE_RCCL = 1 << 1
+NOALLOC_SCRATCH_BYTES = 64 << 20
 STATUS_NOT_STARTED, STATUS_COPY_NEAR_PIXEL, STATUS_UNSTABLE, STATUS_FINAL = 0, 1, 2, 3  # GenerationStatus, lib.rs:59-64
 
 _d3 = C.c_double * 3
@@ -97,6 +98,7 @@ SYMBOLS = {
     "rthip_render": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, _P(Stats)]),
     "rthip_render_device": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]),
     "rthip_reset_accum": (C.c_int, [C.c_void_p]),
+    "rthip_render_device_noalloc": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]),
     "rthip_pixel_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "rthip_accum_layout": (C.c_int, [C.c_void_p, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint64)]),
     "rthip_group_create": (C.c_int, [_P(C.c_int), C.c_int, C.c_uint32, _P(C.c_void_p)]),

@@ -144,3 +144,6 @@ enum {
     RT_STAT_HIT0 = 6 /* +kind, 4 slots */, RT_STAT_SKY = 10, RT_STAT_SHADOW = 11, RT_STAT_PIX_TRACED = 12, RT_STAT_PIX_FINAL = 13, RT_STAT_N = 14
 };
 #define RT_STAT_SHARDS 256 /* 129 600 waves at 4K bump each counter once: few shards serialise in L2 */
+// rthip_render_device_noalloc: layout of the static scratch array (RTHIP_NOALLOC_SCRATCH_BYTES, include/rthip.h):
+// [0, RT_NOALLOC_STATS_BYTES) the counter shards, then the partial sums of a sliced launch
+#define RT_NOALLOC_STATS_BYTES 32768u /* >= RT_STAT_SHARDS * RT_STAT_N * 8 = 28 672, a multiple of 256 */

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
 
 #include "../../include/rthip.h"
 #include "rt_device.h"
@@ -1316,6 +1317,33 @@ extern "C" hipError_t rt_launch_deinterleave(void *full, const void *recv, const
     hipLaunchKernelGGL(deinterleave_kernel, dim3(bx > 64u ? 64u : bx, height), dim3(256), 0, stream, (uint32_t *)full, (const uint32_t *)recv,
                        (const uint32_t *)own, units, height, band_rows, ndev, pad_rows);
     return hipGetLastError();
+}
+
+// ---- rthip_render_device_noalloc: the scratch of callers that cannot allocate ---------------------------------------
+// A file-scope device array, one copy per GPU, held until the process ends. In host code its NAME is a host-side stand-in,
+// not a device address: the address comes from hipGetSymbolAddress, once per device with that device current
+// (rt_scratch_init, called by rthip_create), and host code only ever uses that pointer (kernel arguments, hipMemsetAsync).
+static_assert(RT_NOALLOC_STATS_BYTES >= RT_STAT_SHARDS * RT_STAT_N * sizeof(unsigned long long) && RT_NOALLOC_STATS_BYTES % 256 == 0, "scratch layout");
+static __device__ __align__(256) unsigned char scratch[RTHIP_NOALLOC_SCRATCH_BYTES];
+#define RT_MAX_DEVICES 64
+static void *g_scratch_ptr[RT_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+// the calling thread's current device must be `device`
+extern "C" hipError_t rt_scratch_init(int device) {
+    if (device < 0 || device >= RT_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    g_scratch_ptr[device] = ptr;
+    return hipSuccess;
+}
+extern "C" void *rt_scratch_ptr(int device) {
+    if (device < 0 || device >= RT_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    return g_scratch_ptr[device];
 }
 
 extern "C" hipError_t rt_launch_pick(const KernelParams *P, float u, float v, long long *d_out, hipStream_t stream) {

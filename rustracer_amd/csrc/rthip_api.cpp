@@ -18,6 +18,8 @@
 extern "C" hipError_t rt_launch_render(const KernelParams *P, int count_stats, hipStream_t stream);
 extern "C" hipError_t rt_launch_compact(const KernelParams *P, uint32_t *list, uint32_t *count, hipStream_t stream);
 extern "C" hipError_t rt_launch_pick(const KernelParams *P, float u, float v, long long *d_out, hipStream_t stream);
+extern "C" hipError_t rt_scratch_init(int device);
+extern "C" void *rt_scratch_ptr(int device);
 
 namespace {
 
@@ -54,6 +56,8 @@ struct rthip_ctx {
     bool pending_stats = false, pending_adaptive = false;  // a counting pass has been enqueued and not yet collected
     uint32_t pending_rows = 0, pending_width = 0;
     unsigned long long *stats_host = nullptr;  // page-locked landing buffer of the counter shards (no staging allocation per pass)
+    void *scratch = nullptr;                   // this device's copy of the static scratch array (rthip_render_device_noalloc)
+    const void *acc_buffer = nullptr;          // where the running sum lives: ctx->accum.p, or the caller's d_accum (no-alloc passes)
 };
 
 namespace {
@@ -248,6 +252,10 @@ int rthip_create(int device, rthip_ctx **out_ctx) {
         HIPCHK(ctx, hipMalloc(&ctx->pick_out.p, sizeof(long long)));
         ctx->pick_out.bytes = sizeof(long long);
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->stats_host, RT_STAT_SHARDS * RT_STAT_N * sizeof(unsigned long long), hipHostMallocDefault));
+        // the device address of the static scratch array, once per device, with that device current (each GPU holds its own copy)
+        HIPCHK(ctx, rt_scratch_init(device));
+        ctx->scratch = rt_scratch_ptr(device);
+        if (!ctx->scratch) return fail(ctx, RTHIP_E_INTERNAL, "the scratch array has no device address");
         return RTHIP_OK;
     }();
     if (st != RTHIP_OK) {
@@ -511,7 +519,9 @@ int rthip_pixel_status(rthip_ctx *ctx, uint8_t *status_out, uint8_t *same_color_
     }
 }
 
-// One pass, enqueued on `hip_stream`.
+// One pass, enqueued on `hip_stream`. noalloc = the rthip_render_device_noalloc contract: no hipMalloc/hipFree (nor any
+// allocating routine) on this path — the running sum lives in the caller's d_accum, the counter shards and the partial sums
+// of a sliced launch in this device's copy of the static scratch array (ctx->scratch), and the sizes are checked, not grown.
 // Second half of a pass that counts: waits for the pass, sums the counter shards (they landed in the context's page-locked
 // buffer) and reads the kernel time. Split from the enqueue so that a multi-device caller can start every device first.
 static int collect_stats(rthip_ctx *ctx, rthip_stats *stats) {
@@ -543,7 +553,7 @@ static int collect_stats(rthip_ctx *ctx, rthip_stats *stats) {
     return RTHIP_OK;
 }
 
-static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgba8, void *d_accum, void *hip_stream, rthip_stats *stats,
+static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgba8, void *d_accum, void *hip_stream, rthip_stats *stats, bool noalloc,
                        bool defer_stats = false) {
     if (!ctx) return RTHIP_E_BADARG;
     try {
@@ -555,6 +565,10 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         if ((st = owned_rows(p, &rows))) return fail(ctx, st, "bad band parameters");
         if ((p->flags & RTHIP_F_POINT_LIGHTS) && ctx->base.n_lights == 0) return fail(ctx, RTHIP_E_STATE, "RTHIP_F_POINT_LIGHTS without lights in the scene");
         const bool adaptive = (p->flags & RTHIP_F_ADAPTIVE) != 0;
+        if (noalloc && adaptive)
+            return fail(ctx, RTHIP_E_BADARG, "rthip_render_device_noalloc: RTHIP_F_ADAPTIVE is not supported (the per-pixel convergence state is context-owned memory that grows with the image)");
+        if (noalloc && !d_accum && rows)
+            return fail(ctx, RTHIP_E_BADARG, "rthip_render_device_noalloc: d_accum is required (it holds the running sum; the context allocates none on this path)");
         hipStream_t stream = (hipStream_t)hip_stream;
         HIPCHK(ctx, hipSetDevice(ctx->device));
         const bool same_layout = ctx->acc_width == p->width && ctx->acc_height == p->height && ctx->acc_rows == rows &&
@@ -570,7 +584,11 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
             if (stats) std::memset(stats, 0, sizeof *stats);
             return RTHIP_OK;
         }
-        if ((st = ensure(ctx, ctx->accum, size_t(rows) * p->width * 3 * sizeof(float)))) return st;
+        if (!noalloc && (st = ensure(ctx, ctx->accum, size_t(rows) * p->width * 3 * sizeof(float)))) return st;
+        // where the running sum lives: the context's buffer, or (allocation-free passes) the caller's d_accum
+        const void *acc_buffer = noalloc ? (const void *)d_accum : (const void *)ctx->accum.p;
+        if (accumulate && acc_buffer != ctx->acc_buffer)
+            return fail(ctx, RTHIP_E_STATE, "RTHIP_F_ACCUMULATE: the running sum of this context lives in another buffer (allocation-free passes keep it in the caller's d_accum)");
 
         KernelParams k = ctx->base;
         k.width = p->width, k.height = p->height;
@@ -582,10 +600,11 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         k.band_rows = p->band_rows, k.band_first = p->band_first, k.band_stride = p->band_stride, k.owned_rows = rows;
         k.accumulate = accumulate ? 1u : 0u;
         k.inv_nb = float(1.0 / double(prior + p->spp));
-        k.accum = (float *)ctx->accum.p;
-        k.accum_out = (float *)d_accum;
+        k.accum = noalloc ? (float *)d_accum : (float *)ctx->accum.p;
+        k.accum_out = noalloc ? nullptr : (float *)d_accum;
         k.rgba8 = (uint32_t *)d_rgba8;
-        unsigned long long *d_stats = (unsigned long long *)ctx->stats.p;
+        unsigned char *scratch = (unsigned char *)ctx->scratch;  // the device address from hipGetSymbolAddress, never the array's name
+        unsigned long long *d_stats = noalloc ? (unsigned long long *)scratch : (unsigned long long *)ctx->stats.p;
         k.stats = stats ? d_stats : nullptr;  // no reader, no counting
         if (p->flags & RTHIP_F_NO_BVH) k.n_bvh_nodes = 0;
         // sample slicing: a function of spp alone, so that the image is the same for every band layout / GPU count
@@ -598,8 +617,17 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         if (groups >= RT_SLICE_BELOW_BLOCKS) k.n_slices = 1;
         if (k.n_slices > 1) {
             const size_t need = size_t(k.n_slices) * rows * p->width * 3 * sizeof(float);
-            if ((st = ensure(ctx, ctx->partial, need))) return st;
-            k.partial = (float *)ctx->partial.p;
+            if (noalloc) {
+                if (need > RTHIP_NOALLOC_SCRATCH_BYTES - RT_NOALLOC_STATS_BYTES)
+                    return fail(ctx, RTHIP_E_BADARG, "rthip_render_device_noalloc: this launch is sample-sliced and needs " + std::to_string(need) +
+                                                         " bytes of partial sums; the static scratch holds " +
+                                                         std::to_string(size_t(RTHIP_NOALLOC_SCRATCH_BYTES - RT_NOALLOC_STATS_BYTES)) +
+                                                         " (use fewer rows per call, spp <= 64 per pass, or rthip_render_device)");
+                k.partial = (float *)(scratch + RT_NOALLOC_STATS_BYTES);  // fully written by the render kernel before resolve_kernel reads it
+            } else {
+                if ((st = ensure(ctx, ctx->partial, need))) return st;
+                k.partial = (float *)ctx->partial.p;
+            }
         }
 
         // passes share the context's buffers (running sum, counters, partial sums, work-list): a pass enqueued on another
@@ -629,6 +657,7 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         ctx->acc_band_rows = p->band_rows, ctx->acc_band_first = p->band_first, ctx->acc_band_stride = p->band_stride;
         ctx->nb_samples = prior + p->spp;
         ctx->adaptive = adaptive;
+        ctx->acc_buffer = acc_buffer;
 
         if (stats) {
             HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, d_stats, RT_STAT_SHARDS * RT_STAT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -644,12 +673,12 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
 }
 
 int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgba8, void *d_accum, void *hip_stream, rthip_stats *stats) {
-    return render_pass(ctx, p, d_rgba8, d_accum, hip_stream, stats);
+    return render_pass(ctx, p, d_rgba8, d_accum, hip_stream, stats, false);
 }
 
 // internal (rthip_group.cpp): enqueue a pass on the context's own stream without waiting for its counters / wait and read them
 int rt_ctx_render_deferred(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgba8, void *d_accum, rthip_stats *stats_wanted) {
-    return render_pass(ctx, p, d_rgba8, d_accum, ctx ? ctx->stream : nullptr, stats_wanted, true);
+    return render_pass(ctx, p, d_rgba8, d_accum, ctx ? ctx->stream : nullptr, stats_wanted, false, true);
 }
 int rt_ctx_collect_stats(rthip_ctx *ctx, rthip_stats *stats) {
     if (!ctx || !stats) return RTHIP_E_BADARG;
@@ -658,6 +687,10 @@ int rt_ctx_collect_stats(rthip_ctx *ctx, rthip_stats *stats) {
 void *rt_ctx_stream(rthip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int rt_ctx_device(rthip_ctx *ctx) { return ctx ? ctx->device : -1; }
 uint64_t rt_ctx_nb_samples(rthip_ctx *ctx) { return ctx ? ctx->nb_samples : 0; }
+
+int rthip_render_device_noalloc(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgba8, void *d_accum, void *hip_stream, rthip_stats *stats) {
+    return render_pass(ctx, p, d_rgba8, d_accum, hip_stream, stats, true);
+}
 
 int rthip_render(rthip_ctx *ctx, const rthip_render_params *p, uint8_t *rgba8_out, float *accum_out, rthip_stats *stats) {
     if (!ctx) return RTHIP_E_BADARG;

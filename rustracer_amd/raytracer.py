@@ -218,6 +218,14 @@ class Raytracer:
         _check(self._lib.rthip_accum_layout(self._ctx, C.byref(rows), C.byref(width), C.byref(nb)), self._ctx)
         return rows.value, width.value, nb.value
 
+    def render_device_noalloc(self, params: abi.RenderParams, d_rgba8, d_accum, stream=0, want_stats=False):
+        """rthip_render_device_noalloc: the pass for callers that cannot allocate; the running sum lives in d_accum."""
+        self._sync_scene_camera(None)
+        st = abi.Stats()
+        _check(self._lib.rthip_render_device_noalloc(self._ctx, C.byref(params), d_rgba8 or None, d_accum or None, stream or None,
+                                                     C.byref(st) if want_stats else None), self._ctx)
+        return st.as_dict() if want_stats else None
+
     def invalidate_pixels(self):
         _check(self._lib.rthip_reset_accum(self._ctx), self._ctx)
 

@@ -80,6 +80,7 @@ def test_status_strings_and_null_handling():
     assert lib.rthip_create(0, None) == abi.E_BADARG
     assert lib.rthip_render(None, None, None, None, None) == abi.E_BADARG
     assert lib.rthip_upload_scene(None, None) == abi.E_BADARG
+    assert lib.rthip_render_device_noalloc(None, None, None, None, None, None) == abi.E_BADARG
     assert lib.rthip_group_render(None, None, None, None, None) == abi.E_BADARG and lib.rthip_group_size(None) == 0
     assert b"RCCL" in lib.rthip_status_string(abi.E_RCCL)
     lib.rthip_destroy(None)  # no-op
