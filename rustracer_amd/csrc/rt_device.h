@@ -46,6 +46,8 @@ struct DevTexInfo {
     uint32_t width, height;
     uint32_t tiles_per_row;  // ceil(width/8)
     uint32_t first_texel;    // offset into texels (in u32)
+    uint32_t magic_w, magic_h;  // floor(2^32 / width), floor(2^32 / height) (0xffffffff for 1): Texture::wrap's `%` without a division
+    uint32_t _pad0, _pad1;
 };
 
 struct DevLight { float px, py, pz, _p0, ir, ig, ib, _p1; };
@@ -99,6 +101,8 @@ struct KernelParams {
     float hx, hy, hz;
     float vx, vy, vz;
     float inv_wm1, inv_hm1;  // 1/(width-1), 1/(height-1)   lib.rs:283,285
+    float hwx, hwy, hwz;     // horizontal / (width-1): the direction change per unit of x jitter
+    float vhx, vhy, vhz;     // vertical / (height-1)
     float inv_nb;            // 1/nb_samples                lib.rs:294
     uint32_t width, height;
     uint32_t spp, max_depth, seed, sample0, flags;

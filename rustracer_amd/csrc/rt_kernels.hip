@@ -37,9 +37,22 @@
 #include "rt_rng.h"
 
 #define RT_NONE 0xffffffffu
+#ifndef RT_SCAN_UNROLL
+#define RT_SCAN_UNROLL 4u  /* MODE_LDS: spheres per group of the closest-hit scan; divides RT_LDS_SPHERES */
+#endif
+#ifndef RT_SCAN_PRELOAD
+#define RT_SCAN_PRELOAD 0
+#endif
+#ifndef RT_SCAN_PIN_NTMIN
+#define RT_SCAN_PIN_NTMIN 0
+#endif
+#ifndef RT_SCAN_TAKE_BALLOT
+#define RT_SCAN_TAKE_BALLOT 0
+#endif
 
 enum { MODE_LDS = 0, MODE_BVH = 1, MODE_GLOBAL = 2 };
 
+typedef float lds_f4 __attribute__((ext_vector_type(4)));  // 16-byte aligned: LDS reads through it are ds_read_b128
 struct f3 {
     float x, y, z;
 };
@@ -360,24 +373,55 @@ __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &
     if (MODE == MODE_LDS) {
         // tracked negated: nbest = -h.t, starting just above -tmax, so "not (n < nbest)" <=> t <= best < tmax
         float nbest = -h.t;
-        const float ntmin = -r.tmin;
-        for (uint32_t i = 0; i < P.n_spheres; i++) {  // wave-uniform LDS address: broadcast read, VGPR operands
-            const rt_f4 g = s_geom[i];
-            const f3 oc = mk3(r.o.x - g.x, r.o.y - g.y, r.o.z - g.z);
-            const float half_b = dot(oc, r.d);
-            float c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -g.w)));
-            c = (i == self) ? 0.0f : c;  // sphere_roots: exact c for the sphere the ray starts on
-            const float disc = fmaf(half_b, half_b, -c);
-            // most spheres are missed by every ray of the wave (coherent primary rays, small spheres): then the square root,
-            // both roots and the window/closest selects (half of the test, ~40 issue cycles) are skipped. A lane's own result
-            // never depends on its neighbours: with disc < 0 (or NaN) the skipped code selects nothing either.
-            if (__ballot(disc >= 0.0f) == 0ull) continue;
-            const float root = fast_sqrt(disc);
-            const float n0 = half_b + root, n1 = half_b - root;
-            const float n = (n0 < ntmin) ? n0 : n1;
-            const bool take = (n1 < ntmin) & !(n < nbest);
-            nbest = take ? n : nbest;
-            h.shape = take ? i : h.shape;
+        float ntmin = -r.tmin;
+#if RT_SCAN_PIN_NTMIN
+        asm volatile("" : "+v"(ntmin));  // a register holding -tmin: the compares stay in the short VOPC encoding (no source modifier)
+#endif
+        // The staged array is padded to a multiple of RT_SCAN_UNROLL with spheres that cannot be hit (NaN centre: the discriminant
+        // is NaN), so the loop runs in groups of RT_SCAN_UNROLL with constant LDS offsets and constant indices (one address
+        // register per group instead of an address and an index move per sphere; the group's broadcast reads issue together).
+        for (uint32_t base = 0; base < P.n_spheres; base += RT_SCAN_UNROLL) {  // wave-uniform LDS address: broadcast read, VGPR operands
+            // the group's LDS address in ONE vector register (opaque to the compiler, or it re-creates the address from the
+            // scalar loop counter before every read)
+            uint32_t grp_addr = uint32_t(size_t((const __attribute__((address_space(3))) rt_f4 *)s_geom)) + base * 16u;
+            asm volatile("" : "+v"(grp_addr));
+            const __attribute__((address_space(3))) lds_f4 *grp_geom = (const __attribute__((address_space(3))) lds_f4 *)uintptr_t(grp_addr);
+#if RT_SCAN_PRELOAD
+            lds_f4 pre[RT_SCAN_UNROLL];  // the group's reads issue together, ahead of the first test
+#pragma unroll
+            for (uint32_t k = 0; k < RT_SCAN_UNROLL; k++) {
+                pre[k] = grp_geom[k];
+                asm volatile("" : "+v"(pre[k]));
+            }
+#endif
+#pragma unroll
+            for (uint32_t k = 0; k < RT_SCAN_UNROLL; k++) {
+                const uint32_t i = base + k;
+#if RT_SCAN_PRELOAD
+                const lds_f4 gv = pre[k];
+#else
+                const lds_f4 gv = grp_geom[k];  // one ds_read_b128 (16-byte aligned vector type)
+#endif
+                const rt_f4 g = rt_f4{gv.x, gv.y, gv.z, gv.w};
+                const f3 oc = mk3(r.o.x - g.x, r.o.y - g.y, r.o.z - g.z);
+                const float half_b = dot(oc, r.d);
+                float c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -g.w)));
+                c = (i == self) ? 0.0f : c;  // sphere_roots: exact c for the sphere the ray starts on
+                const float disc = fmaf(half_b, half_b, -c);
+                // most spheres are missed by every ray of the wave (coherent primary rays, small spheres): then the square root,
+                // both roots and the window/closest selects (half of the test, ~40 issue cycles) are skipped. A lane's own result
+                // never depends on its neighbours: with disc < 0 (or NaN) the skipped code selects nothing either.
+                if (__ballot(disc >= 0.0f) == 0ull) continue;
+                const float root = fast_sqrt(disc);
+                const float n0 = half_b + root, n1 = half_b - root;
+                const float n = (n0 < ntmin) ? n0 : n1;
+                const bool take = (n1 < ntmin) & !(n < nbest);
+#if RT_SCAN_TAKE_BALLOT
+                if (__ballot(take) == 0ull) continue;  // nobody's closest hit changes: skip the two selects
+#endif
+                nbest = take ? n : nbest;
+                h.shape = take ? i : h.shape;
+            }
         }
         h.t = -nbest;
     } else if (MODE == MODE_GLOBAL) {
@@ -467,12 +511,38 @@ __device__ __forceinline__ f3 random_unit_vector(uint32_t h) {
 }
 
 // Texture::wrap — texture.rs:32-41 (`as i32`: truncate, saturate, NaN -> 0)
-__device__ __forceinline__ uint32_t texture_wrap(float val, float scale, uint32_t bound) {
-    float fc = val * scale * float(bound);
-    int32_t ic = (fc == fc) ? int32_t(fminf(fmaxf(fc, -2147483648.0f), 2147483520.0f)) : 0;
-    if (fc >= 2147483648.0f) ic = 2147483647;
-    int32_t w = ic % int32_t(bound);
-    return uint32_t(w < 0 ? w + int32_t(bound) : w);
+// The cast is the hardware's v_cvt_i32_f32 (saturating, NaN -> 0: exactly Rust's `as i32`); the remainder uses the texture's
+// precomputed magic = floor(2^32 / bound) (DevTexInfo): q = mulhi(|ic|, magic) is the quotient or one below it, so one
+// correction makes it exact for every |ic| <= 2^31 — 12 instructions instead of the 40 of a generic signed 32-bit `%`.
+__device__ __forceinline__ uint32_t texture_wrap(float val, float scale, uint32_t bound, uint32_t magic) {
+    const float fc = val * scale * float(bound);
+    int32_t ic;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(ic) : "v"(fc));
+    const uint32_t a = ic < 0 ? 0u - uint32_t(ic) : uint32_t(ic);  // |ic| (2^31 for INT_MIN)
+    uint32_t rem = a - __umulhi(a, magic) * bound;
+    rem = rem >= bound ? rem - bound : rem;
+    // Rust: w = ic % bound keeps the sign of ic; if w < 0 { w + bound }
+    return (ic < 0 && rem != 0u) ? bound - rem : rem;
+}
+// atan2(y, x) for finite arguments (sphere.rs:70; the arguments are components of p - c): the odd minimax polynomial of the
+// ROCm device library's atan2f on min/max, then the octant fix-ups — without that routine's handling of infinities, NaN classes
+// and denormal scaling (~20 instructions less). atan2(0, 0) = 0 like libm.
+__device__ __forceinline__ float atan2_finite(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * fast_rcp(fmaxf(mx, 1e-37f));
+    const float s2 = t * t;
+    float q = fmaf(s2, 0x1.5a54bp-9f, -0x1.f4b218p-7f);
+    q = fmaf(s2, q, 0x1.53f67ep-5f);
+    q = fmaf(s2, q, -0x1.2fa9aep-4f);
+    q = fmaf(s2, q, 0x1.b26364p-4f);
+    q = fmaf(s2, q, -0x1.22c1ccp-3f);
+    q = fmaf(s2, q, 0x1.99717ep-3f);
+    q = fmaf(s2, q, -0x1.5554c4p-2f);
+    float a = fmaf(t, s2 * q, t);
+    a = ay > ax ? 1.57079637f - a : a;
+    a = x < 0.0f ? 3.14159274f - a : a;
+    return __builtin_copysignf(a, y);
 }
 
 // what shading needs to know about the surface that was hit
@@ -551,11 +621,14 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 #ifndef RT_BVH_LIGHT_WAVES
 #define RT_BVH_LIGHT_WAVES 5
 #endif
+#ifndef RT_SCAN_WAVES
+#define RT_SCAN_WAVES 7
+#endif
 #ifndef RT_BVH_WAVES
 #define RT_BVH_WAVES 7
 #endif
 template <bool STATS, int MODE, bool LIGHTS>
-__global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_BVH_LIGHT_WAVES : RT_SCAN_LIGHT_WAVES) : (MODE == MODE_BVH ? RT_BVH_WAVES : 7))) void render_kernel(const KernelParams P) {
+__global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_BVH_LIGHT_WAVES : RT_SCAN_LIGHT_WAVES) : (MODE == MODE_BVH ? RT_BVH_WAVES : RT_SCAN_WAVES))) void render_kernel(const KernelParams P) {
     constexpr bool POOL = MODE == MODE_BVH;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     rt_f4 *s_geom_mem = (rt_f4 *)s_dyn;
@@ -565,7 +638,11 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
     float *s_L_all = (float *)(s_pix_all + 256);
     const rt_f4 *s_geom = s_geom_mem;
     if (MODE == MODE_LDS) {
-        for (uint32_t i = threadIdx.x; i < P.n_spheres; i += 256) s_geom_mem[i] = P.sph_geom[i];
+        const uint32_t n_padded = (P.n_spheres + RT_SCAN_UNROLL - 1u) & ~(RT_SCAN_UNROLL - 1u);
+        for (uint32_t i = threadIdx.x; i < n_padded; i += 256)
+            // padding: never hit. The centre is NaN, not just r*r = -inf: a padding index can equal `self` when the ray starts on a
+            // plane or triangle (their shape ids follow the spheres'), which replaces c by 0 — a NaN half_b keeps the discriminant NaN
+            s_geom_mem[i] = i < P.n_spheres ? P.sph_geom[i] : rt_f4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), -__builtin_inff()};
         for (uint32_t i = threadIdx.x; i < 3 * P.n_spheres; i += 256) s_shade_mem[i] = P.sph_shade[i];
         __syncthreads();
     }
@@ -630,6 +707,8 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             pp_own = pp;
         }
         const f3 cam_o = mk3(P.ox, P.oy, P.oz);
+        f3 cam_v = cam_o;  // ... in vector registers: operand of the select in next_ray (the lane mask already takes the one scalar operand)
+        asm volatile("" : "+v"(cam_v.x), "+v"(cam_v.y), "+v"(cam_v.z));
         f3 acc = mk3(0.0f, 0.0f, 0.0f);
         // ---- state of the path this lane is tracing ----
         uint32_t item = 0;   // radiance slot of the work item: ring row << 6 | pixel
@@ -655,8 +734,10 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
         BvhDeep deep;
         bs.ref = RT_BVH_DONE, bs.sp = 0, bs.inv_d = bs.noi = mk3(0.0f, 0.0f, 0.0f);
         bool tracing = false;  // ... and this lane's ray is still inside the tree
-        // what shade() leaves behind for next_ray(): the hit point, the surface and the mirror direction
-        f3 p = cam_o, refl = mk3(0.0f, 0.0f, 0.0f);
+        // what shade() leaves behind for next_ray(): the hit point (IN r.o: the ray's origin is dead once its hit is known, and the
+        // next ray starts there — no copy at the loop's join), the surface and the mirror direction
+        f3 &p = r.o;
+        f3 refl = mk3(0.0f, 0.0f, 0.0f);
         float cosi = 0.0f;
         Surface sf;
         sf.n = sf.tm = mk3(0.0f, 0.0f, 0.0f), sf.param = sf.r1 = sf.inv_ior = sf.tu = sf.tv = sf.tw = 0.0f, sf.kind = sf.mat = 0;
@@ -701,7 +782,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 if (STATS) cnt[RT_STAT_SHADOW]++;
                 // the shadow ray replaces the lane's ray: next_ray() builds the scattered ray from p, the surface and refl alone
                 // (lit surfaces are not dielectric)
-                r.o = p, r.d = ldir;
+                r.d = ldir;  // (origin: p is r.o already)
                 const float dist = dist2 * rdist;
                 r.tmin = RT_T_MIN * dist, r.tmax = dist;
                 lsc = w * fast_rcp(dist2);
@@ -766,12 +847,12 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 done = true;
                 if (STATS) cnt[RT_STAT_SKY]++;
             } else {
-                p = fma3(r.d, h.t, r.o);  // ray.rs:30-32
+                r.o = fma3(r.d, h.t, r.o);  // ray.rs:30-32: the hit point p (an alias of r.o, see above)
                 // ---- the surface: normal + material (collision.rs:29-43) ----
                 if (h.shape < P.n_spheres) {
                     rt_f4 r0, r1, r2;
                     if constexpr (MODE == MODE_LDS) {  // kept apart so that the LDS reads stay ds_read_b128 (no generic pointer)
-                        const rt_f4 *rec = s_shade_mem + 3 * h.shape;
+                        const rt_f4 *rec = (const rt_f4 *)((const unsigned char *)s_shade_mem + __umul24(h.shape, 48u));  // 32-bit address math
                         r0 = rec[0], r1 = rec[1], r2 = rec[2];
                         // pin the loaded values: otherwise the loads are sunk to their uses and merged with the
                         // material loads of the non-sphere branch into per-dword flat loads
@@ -814,7 +895,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     // Texture::scatter — texture.rs:45-57; bounce -> None (texture.rs:59-61) => path ends, ray.rs:80
                     float U, V;
                     if (h.shape < P.n_spheres) {
-                        U = (1.0f + atan2f(sf.tu, sf.tv) * 0.31830988618379067f) * 0.5f;  // sphere.rs:70
+                        U = (1.0f + atan2_finite(sf.tu, sf.tv) * 0.31830988618379067f) * 0.5f;  // sphere.rs:70
                         V = acosf(sf.tw) * 0.31830988618379067f;                          // sphere.rs:71
                     } else if (h.shape < P.n_spheres + P.n_planes) {
                         const uint32_t i = h.shape - P.n_spheres;
@@ -826,8 +907,8 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                         U = h.b1, V = h.b2;
                     }
                     const DevTexInfo ti = P.tex_info[P.materials[sf.mat].texture];
-                    const uint32_t txl = texture_wrap(U, sf.param, ti.width);
-                    const uint32_t tyl = texture_wrap(V, sf.param, ti.height);
+                    const uint32_t txl = texture_wrap(U, sf.param, ti.width, ti.magic_w);
+                    const uint32_t tyl = texture_wrap(V, sf.param, ti.height, ti.magic_h);
                     const uint32_t texel = P.texels[ti.first_texel + (((tyl >> 3) * ti.tiles_per_row + (txl >> 3)) << 6) + ((tyl & 7u) << 3) + (txl & 7u)];
                     const f3 c = mk3(float(texel & 255u), float((texel >> 8) & 255u), float((texel >> 16) & 255u)) * (1.0f / 255.0f);
                     emit(T * c);
@@ -906,12 +987,8 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             f3 nd;
             if (fresh) {
                 // lib.rs:282-285 (x jitter first): u = (x + xi)/(W-1) = x/(W-1) + xi/(W-1), the per-pixel part is precomputed
-                const float ju = ua * P.inv_wm1, jv = ub * P.inv_hm1;
-                nd = mk3(fmaf(P.vx, jv, fmaf(P.hx, ju, pp.x)), fmaf(P.vy, jv, fmaf(P.hy, ju, pp.y)), fmaf(P.vz, jv, fmaf(P.hz, ju, pp.z)));
-                r.o = cam_o;  // camera.rs:43-50
-                T = mk3(1.0f, 1.0f, 1.0f);
-                bounce = 0;
-                self = RT_NONE;
+                // (H/(W-1) and V/(H-1) are precomputed: P.hw*, P.vh*)
+                nd = mk3(fmaf(P.vhx, ub, fmaf(P.hwx, ua, pp.x)), fmaf(P.vhy, ub, fmaf(P.hwy, ua, pp.y)), fmaf(P.vhz, ub, fmaf(P.hwz, ua, pp.z)));
                 if (LIGHTS) Ld = mk3(0.0f, 0.0f, 0.0f);
             } else {
                 // random_unit_vector — lambertian_diffuse.rs:39-45, metal.rs:31-37 (a first, then z); v_sin/v_cos take revolutions
@@ -946,10 +1023,19 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     nd = (prob > ua) ? refl : refr;
                     dead = false;
                 }
-                r.o = p;
-                self = h.shape;
-                bounce++;
             }
+            // The rest of the path state as SELECTS in straight-line code, one v_cndmask each. Written as assignments inside the
+            // two branches (or as C++ selects on the branch condition, which the compiler turns back into that) they become phi
+            // copies on both sides of the join: ~25 moves per iteration. Hence the asm.
+            const unsigned long long fm = __ballot(fresh);
+            asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r.o.x) : "v"(cam_v.x), "s"(fm));  // camera.rs:43-50 | the hit point (already in r.o)
+            asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r.o.y) : "v"(cam_v.y), "s"(fm));
+            asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r.o.z) : "v"(cam_v.z), "s"(fm));
+            asm("v_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(T.x) : "s"(fm));
+            asm("v_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(T.y) : "s"(fm));
+            asm("v_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(T.z) : "s"(fm));
+            bounce = fresh ? 0u : bounce + 1u;
+            asm("v_cndmask_b32_e64 %0, %1, -1, %2" : "=v"(self) : "v"(h.shape), "s"(fm));  // RT_NONE | the shape the ray starts on
             set_dir(nd);
         };
         if constexpr (!POOL) {
@@ -961,7 +1047,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             // The fast loop below evaluates exactly the expressions of next_ray(fresh) + shade() for a miss: same bits.
             bool tile_empty = false;
             if (!STATS && !LIGHTS && MODE == MODE_LDS && P.n_planes == 0 && P.n_tris == 0 && P.max_depth != 0) {
-                const f3 hw = mk3(P.hx * P.inv_wm1, P.hy * P.inv_wm1, P.hz * P.inv_wm1), vh = mk3(P.vx * P.inv_hm1, P.vy * P.inv_hm1, P.vz * P.inv_hm1);
+                const f3 hw = mk3(P.hwx, P.hwy, P.hwz), vh = mk3(P.vhx, P.vhy, P.vhz);
                 const f3 e00 = mk3(pp_own.x, pp_own.y, pp_own.z), e10 = e00 + hw, e01 = e00 + vh, e11 = e10 + vh;
                 const f3 ec = e00 + (hw + vh) * 0.5f;
                 const float lc = fast_sqrt(dot(ec, ec));
@@ -989,8 +1075,8 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     for (uint32_t s = 1; s <= n_spp; s++) {
                         const uint32_t hb = rt_mix32(k);
                         k += RT_RNG_SLOTS * RT_RNG_GOLDEN;
-                        const float ju = rt_unit(hb) * P.inv_wm1, jv = rt_unit(rt_second(hb)) * P.inv_hm1;  // lib.rs:282-285
-                        const f3 nd = mk3(fmaf(P.vx, jv, fmaf(P.hx, ju, pp_own.x)), fmaf(P.vy, jv, fmaf(P.hy, ju, pp_own.y)), fmaf(P.vz, jv, fmaf(P.hz, ju, pp_own.z)));
+                        const float ua = rt_unit(hb), ub = rt_unit(rt_second(hb));  // lib.rs:282-285
+                        const f3 nd = mk3(fmaf(P.vhx, ub, fmaf(P.hwx, ua, pp_own.x)), fmaf(P.vhy, ub, fmaf(P.hwy, ua, pp_own.y)), fmaf(P.vhz, ub, fmaf(P.hwz, ua, pp_own.z)));
                         const float dy = nd.y * fast_rsq(dot(nd, nd));
                         const float t = fmaf(0.5f, dy, 0.5f);  // background_color, ray.rs:89-93
                         const float w = 1.0f - t;

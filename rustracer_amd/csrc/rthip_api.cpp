@@ -394,6 +394,9 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
             const rthip_texture &t = s->textures[i];
             ti[i].width = t.width, ti[i].height = t.height;
             ti[i].tiles_per_row = (t.width + 7) / 8;
+            ti[i].magic_w = t.width == 1 ? 0xffffffffu : uint32_t((1ull << 32) / t.width);
+            ti[i].magic_h = t.height == 1 ? 0xffffffffu : uint32_t((1ull << 32) / t.height);
+            ti[i]._pad0 = ti[i]._pad1 = 0;
             if (total_texels > 0xffffffffull) return fail(ctx, RTHIP_E_BADARG, "textures exceed 2^32 texels");
             ti[i].first_texel = uint32_t(total_texels);
             total_texels += size_t(ti[i].tiles_per_row) * ((t.height + 7) / 8) * 64;
@@ -594,6 +597,8 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         k.width = p->width, k.height = p->height;
         k.inv_wm1 = float(1.0 / (double(p->width) - 1.0));
         k.inv_hm1 = float(1.0 / (double(p->height) - 1.0));
+        k.hwx = k.hx * k.inv_wm1, k.hwy = k.hy * k.inv_wm1, k.hwz = k.hz * k.inv_wm1;
+        k.vhx = k.vx * k.inv_hm1, k.vhy = k.vy * k.inv_hm1, k.vhz = k.vz * k.inv_hm1;
         k.spp = p->spp, k.max_depth = p->max_depth, k.seed = p->seed;
         k.sample0 = uint32_t(prior);
         k.flags = p->flags;

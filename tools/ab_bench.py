@@ -23,11 +23,16 @@ for name, l in libs:
     ctxs.append(ctx)
 out = np.zeros((H, W, 4), np.uint8)
 ref = None
-for rnd in range(4):
+REP = int(os.environ.get("REP", "4"))  # back-to-back launches per library and round: the clocks stay up, the minimum is reported
+for rnd in range(3):
     for (name, l), ctx in zip(libs, ctxs):
         p = make_params(W, H, spp, depth, rnd)
         st = abi.Stats()
+        times = []
+        for _ in range(REP):
+            rc = l.rthip_render(ctx, C.byref(p), None, None, C.byref(st))
+            assert rc == 0, l.rthip_last_error(ctx)
+            times.append(st.kernel_ms)
         rc = l.rthip_render(ctx, C.byref(p), out.ctypes.data, None, C.byref(st))
-        assert rc == 0, l.rthip_last_error(ctx)
         crc = int(out.view(np.uint32).sum(dtype=np.uint64))
-        print(f"round {rnd} {os.path.basename(name):28s} kernel_ms={st.kernel_ms:8.3f} rays={st.rays} -> {st.rays/st.kernel_ms/1e3:9.1f} Mrays/s checksum={crc}")
+        print(f"round {rnd} {os.path.basename(name):28s} kernel_ms min={min(times):8.3f} med={sorted(times)[len(times)//2]:8.3f} rays={st.rays} -> {st.rays/min(times)/1e3:9.1f} Mrays/s checksum={crc}", flush=True)
