@@ -234,7 +234,7 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *params, void 
  *   - the running sum lives in the CALLER's d_accum (required; owned_rows*width*3 floats): RTHIP_F_ACCUMULATE adds to what
  *     that buffer holds from the previous pass of this context (same buffer, same layout, else RTHIP_E_STATE);
  *   - the counter shards behind `stats` and the partial sums of a sample-sliced launch (spp > 64 on a launch of fewer than
- *     20 000 16x16 tiles) live in a static device array of RTHIP_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends.
+ *     20 000 workgroup tiles of 256 pixels) live in a static device array of RTHIP_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends.
  *     A sliced launch needs ceil(spp/slice)*owned_rows*width*12 bytes of it; more than it holds -> RTHIP_E_BADARG.
  *   - RTHIP_F_ADAPTIVE -> RTHIP_E_BADARG (its per-pixel state is context-owned memory that grows with the image).
  * Every call on one GPU, from any context, shares that GPU's array: calls that overlap in time on one GPU race (serialise

@@ -25,6 +25,11 @@
 #ifndef RT_SLICE_BELOW_BLOCKS
 #define RT_SLICE_BELOW_BLOCKS 20000u
 #endif /* launches of fewer workgroups than this are sliced */
+// pixels of a 256-thread workgroup: four 8x8 wave tiles; RT_TILE_W * RT_TILE_H = 256, both multiples of 8
+#ifndef RT_TILE_W
+#define RT_TILE_W 32u
+#endif
+#define RT_TILE_H (256u / RT_TILE_W)
 #define RT_T_MIN 0.001f      /* raytracer_core/src/shapes/ray.rs:5 */
 #define RT_T_MAX 100000.0f   /* raytracer_core/src/shapes/ray.rs:6 */
 

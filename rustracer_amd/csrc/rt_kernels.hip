@@ -1,6 +1,6 @@
 // rt_kernels.hip — gfx950 (CDNA4, wave64) kernels of the rustracer render path.
 //
-// render_kernel<STATS, MODE, LIGHTS>: a 256-thread workgroup = a 16x16 pixel tile, a wave = an 8x8 tile (coherent primary
+// render_kernel<STATS, MODE, LIGHTS>: a 256-thread workgroup = a 32x8 pixel tile, a wave = an 8x8 tile (coherent primary
 // rays => coherent branches). The recursion of Ray::_project_ray (raytracer_core/src/shapes/ray.rs:69-87) is an iterative
 // bounce loop with the path state (ray, throughput, bounce count, RNG counter) in VGPRs, and the `samples` loop of
 // generate_pixel (lib.rs:281-288) is folded into the same loop by path regeneration.
@@ -670,10 +670,14 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
         lrow = oi / P.width;
         x = oi - lrow * P.width;
     } else {
-        const uint32_t tiles_x = (P.width + 15u) >> 4;
+        // a workgroup = RT_TILE_W x RT_TILE_H pixels = its 4 waves' 8x8 tiles side by side (32 x 8): a row of the workgroup is
+        // 128 B of RGBA8 and 384 B of the running sum = whole cache lines that no other workgroup (hence no other XCD's L2)
+        // writes, so the lines leave L2 fully written — with 16 x 16 workgroups a third of the running-sum lines were shared
+        // between two XCDs and every launch read 64 MB back from HBM to complete them
+        const uint32_t tiles_x = (P.width + RT_TILE_W - 1u) / RT_TILE_W;
         const uint32_t tile_x = group % tiles_x, tile_y = group / tiles_x;
-        x = (tile_x << 4) + ((wave & 1u) << 3) + (lane & 7u);
-        lrow = (tile_y << 4) + ((wave >> 1) << 3) + (lane >> 3);
+        x = tile_x * RT_TILE_W + ((wave % (RT_TILE_W / 8u)) << 3) + (lane & 7u);
+        lrow = tile_y * RT_TILE_H + ((wave / (RT_TILE_W / 8u)) << 3) + (lane >> 3);
     }
     // owned local row -> image row y (row bands interleaved over contexts)
     uint32_t y = lrow;
@@ -841,9 +845,8 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 }
             }
             if (h.shape == RT_NONE) {  // ray.rs:85, background_color ray.rs:89-93 (the direction is already unit)
-                const float t = fmaf(0.5f, r.d.y, 0.5f);
-                const float w = 1.0f - t;
-                emit(T * mk3(fmaf(0.5f, t, w), fmaf(0.7f, t, w), w + t));
+                // t = 0.5(d.y + 1); (1-t)(1,1,1) + t(0.5,0.7,1) = (1 - 0.5t, 1 - 0.3t, 1) = (0.75 - 0.25 d.y, 0.85 - 0.15 d.y, 1)
+                emit(mk3(T.x * fmaf(-0.25f, r.d.y, 0.75f), T.y * fmaf(-0.15f, r.d.y, 0.85f), T.z));
                 done = true;
                 if (STATS) cnt[RT_STAT_SKY]++;
             } else {
@@ -885,7 +888,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     const DevMaterial m = P.materials[sf.mat];
                     sf.tm = mk3(m.tr, m.tg, m.tb);
                     sf.param = m.param, sf.kind = m.kind, sf.r1 = m.r1, sf.inv_ior = m.inv_ior;
-                    sf.tu = sf.tv = sf.tw = 0.0f;
+                    // (sf.tu/tv/tw keep whatever an earlier sphere hit left: only sphere textures read them)
                 }
                 if (STATS) {
 #pragma unroll
@@ -1078,9 +1081,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                         const float ua = rt_unit(hb), ub = rt_unit(rt_second(hb));  // lib.rs:282-285
                         const f3 nd = mk3(fmaf(P.vhx, ub, fmaf(P.hwx, ua, pp_own.x)), fmaf(P.vhy, ub, fmaf(P.hwy, ua, pp_own.y)), fmaf(P.vhz, ub, fmaf(P.hwz, ua, pp_own.z)));
                         const float dy = nd.y * fast_rsq(dot(nd, nd));
-                        const float t = fmaf(0.5f, dy, 0.5f);  // background_color, ray.rs:89-93
-                        const float w = 1.0f - t;
-                        f3 L = mk3(fmaf(0.5f, t, w), fmaf(0.7f, t, w), w + t);
+                        f3 L = mk3(fmaf(-0.25f, dy, 0.75f), fmaf(-0.15f, dy, 0.85f), 1.0f);  // background_color, ray.rs:89-93, as in shade()
                         asm volatile("" : "+v"(L.x), "+v"(L.y), "+v"(L.z));
                         grp = grp + L;
                         if ((s & g_mask) == 0u && s != n_spp) {
@@ -1347,7 +1348,7 @@ static uint32_t default_ring_rows() {
 extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats, hipStream_t stream) {
     (void)hipGetLastError();  // hipGetLastError() below must report THIS launch, not an older failure of the thread
     KernelParams P = *Pin;
-    const uint32_t tiles_x = (P.width + 15u) >> 4, tiles_y = (P.owned_rows + 15u) >> 4;
+    const uint32_t tiles_x = (P.width + RT_TILE_W - 1u) / RT_TILE_W, tiles_y = (P.owned_rows + RT_TILE_H - 1u) / RT_TILE_H;
     uint32_t blocks = tiles_x * tiles_y;
     if (P.worklist) blocks = uint32_t((uint64_t(P.owned_rows) * P.width + 255u) / 256u);  // worst case: nothing is Final yet
     if (blocks == 0 || P.spp == 0) return hipSuccess;

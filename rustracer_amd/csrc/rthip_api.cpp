@@ -618,7 +618,7 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         k.n_slices = (p->spp + k.slice_spp - 1) / k.slice_spp;
         // ... but whether the launch IS sliced only depends on its size (rt_launch_render applies the same rule)
         const uint64_t groups = (p->flags & RTHIP_F_ADAPTIVE) && accumulate ? (uint64_t(rows) * p->width + 255u) / 256u
-                                                                             : uint64_t((p->width + 15u) / 16u) * ((rows + 15u) / 16u);
+                                                                             : uint64_t((p->width + RT_TILE_W - 1u) / RT_TILE_W) * ((rows + RT_TILE_H - 1u) / RT_TILE_H);
         if (groups >= RT_SLICE_BELOW_BLOCKS) k.n_slices = 1;
         if (k.n_slices > 1) {
             const size_t need = size_t(k.n_slices) * rows * p->width * 3 * sizeof(float);
