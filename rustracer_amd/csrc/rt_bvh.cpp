@@ -229,6 +229,42 @@ uint32_t rt_build_bvh(const rthip_scene_desc *s, std::vector<DevBvhNode> &nodes,
 }
 
 
+// Renumbers the nodes so that the top of the tree comes first, in breadth-first order (a parent before its children), up to
+// `max_top` inner nodes; the others keep their depth-first order behind them. The traversal kernel stages a PREFIX of the array
+// in LDS (any prefix of a breadth-first order is closed under "parent of"), so a ray's first visits — the ones every ray of a
+// workgroup makes — are LDS reads instead of divergent global loads. Returns the number of nodes in breadth-first order.
+uint32_t rt_bvh_top_first(std::vector<DevBvhNode> &nodes, uint32_t max_top) {
+    const uint32_t n = uint32_t(nodes.size());
+    if (n == 0 || max_top == 0) return 0;
+    std::vector<uint32_t> order;  // new position -> old index
+    order.reserve(n);
+    std::vector<uint8_t> taken(n, 0);
+    order.push_back(0);
+    taken[0] = 1;
+    for (size_t head = 0; head < order.size() && order.size() < max_top; head++) {
+        const DevBvhNode &nd = nodes[order[head]];
+        for (uint32_t ref : {nd.ref0, nd.ref1}) {
+            if ((ref & RT_BVH_LEAF_BIT) || ref >= n || taken[ref] || order.size() >= max_top) continue;
+            taken[ref] = 1;
+            order.push_back(ref);
+        }
+    }
+    const uint32_t n_top = uint32_t(order.size());
+    for (uint32_t i = 0; i < n; i++)
+        if (!taken[i]) order.push_back(i);
+    std::vector<uint32_t> new_index(n);
+    for (uint32_t pos = 0; pos < n; pos++) new_index[order[pos]] = pos;
+    std::vector<DevBvhNode> out(n);
+    for (uint32_t pos = 0; pos < n; pos++) {
+        DevBvhNode nd = nodes[order[pos]];
+        if (!(nd.ref0 & RT_BVH_LEAF_BIT)) nd.ref0 = new_index[nd.ref0];
+        if (!(nd.ref1 & RT_BVH_LEAF_BIT)) nd.ref1 = new_index[nd.ref1];
+        out[pos] = nd;
+    }
+    nodes.swap(out);
+    return n_top;
+}
+
 namespace {
 inline uint32_t f_bits(float x) { uint32_t u; std::memcpy(&u, &x, 4); return u; }
 inline float bits_f(uint32_t u) { float x; std::memcpy(&x, &u, 4); return x; }

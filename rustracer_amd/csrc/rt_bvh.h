@@ -23,3 +23,6 @@ bool rt_bvh_quantize(const std::vector<DevBvhNode> &nodes, std::vector<DevBvhNod
 double rt_bvh_dequantize(uint32_t frame, uint32_t q8);
 // returns the number of traversal stack levels the tree needs (<= RT_BVH_MAX_DEPTH), 0 for an empty scene
 uint32_t rt_build_bvh(const rthip_scene_desc *scene, std::vector<DevBvhNode> &nodes, std::vector<uint32_t> &prims);
+// top of the tree first, breadth-first (see rt_bvh.cpp); returns how many nodes are in that order
+#define RT_BVH_TOP_MAX 255u
+uint32_t rt_bvh_top_first(std::vector<DevBvhNode> &nodes, uint32_t max_top);

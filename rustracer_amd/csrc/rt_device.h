@@ -116,6 +116,8 @@ struct KernelParams {
     // scene
     uint32_t n_spheres, n_planes, n_tris, n_lights, n_bvh_nodes;
     uint32_t bvh_levels;  // traversal stack levels = depth of the tree
+    uint32_t bvh_top_nodes;  // nodes [0, bvh_top_nodes) are the top of the tree in breadth-first order; the render kernel stages
+                             // min(bvh_top_nodes, its LDS budget) of them in LDS (rt_launch_render)
     uint32_t ring_rows;   // MODE_BVH: sample rows in a wave's radiance ring, a power of two <= 16 (set by rt_launch_render)
     const rt_f4 *sph_geom;
     const rt_f4 *sph_shade;

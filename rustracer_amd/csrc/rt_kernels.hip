@@ -53,6 +53,7 @@
 enum { MODE_LDS = 0, MODE_BVH = 1, MODE_GLOBAL = 2 };
 
 typedef float lds_f4 __attribute__((ext_vector_type(4)));  // 16-byte aligned: LDS reads through it are ds_read_b128
+typedef uint32_t lds_u4 __attribute__((ext_vector_type(4)));
 struct f3 {
     float x, y, z;
 };
@@ -190,6 +191,9 @@ __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
 #ifndef RT_BVH_LDS_LEVELS
 #define RT_BVH_LDS_LEVELS 8u
 #endif
+#ifndef RT_BVH_TOP_NODES
+#define RT_BVH_TOP_NODES 0  /* > 0: stage that many nodes of the top of the tree in LDS — measured slower at every size */
+#endif
 #ifndef RT_BVH_LEAF_LANES
 #define RT_BVH_LEAF_LANES 16
 #endif
@@ -218,7 +222,7 @@ __device__ __forceinline__ bool slab_from_t(float ax, float bx, float ay, float 
 // ANY: 0 = closest-hit query, 1 = any-hit query, 2 = per lane (any_lane): closest-hit and shadow rays of a wave walk the tree together
 template <bool STATS, int ANY, bool YIELD>
 __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uint32_t self, HitRec &h, BvhState &s, BvhDeep &deep, uint32_t *cnt, uint32_t *s_stack,
-                                        bool any_lane = false) {
+                                        bool any_lane = false, const lds_u4 *s_top = nullptr, uint32_t n_top = 0) {
     const bool any = ANY == 2 ? any_lane : (ANY == 1);
     const uint4 *nodes = (const uint4 *)P.bvh_nodes;  // DevBvhNodeQ: 2 x 16 bytes
     uint32_t ref = s.ref;
@@ -260,7 +264,21 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
           }
 #endif
           if (ref < RT_BVH_DONE) {
-            const uint4 na = nodes[2 * ref], nb = nodes[2 * ref + 1];  // {frame x, y, z, ref0} {q x, y, z, ref1}
+            // {frame x, y, z, ref0} {q x, y, z, ref1}. RT_BVH_TOP_NODES > 0: the first n_top nodes (the top of the tree, breadth-first)
+            // are staged in LDS
+            uint4 na, nb;
+#if RT_BVH_TOP_NODES > 0
+            // (measured and rejected, DESIGN.md §5: the lanes of a wave sit at all depths of the tree, so a visit issues BOTH the
+            // LDS and the global path; the code is kept behind the macro for the record)
+            if (n_top != 0u && ref < n_top) {
+                const lds_u4 a = s_top[2 * ref], b = s_top[2 * ref + 1];
+                na = make_uint4(a.x, a.y, a.z, a.w), nb = make_uint4(b.x, b.y, b.z, b.w);
+                asm volatile("" : "+v"(na.x), "+v"(na.y), "+v"(na.z), "+v"(na.w), "+v"(nb.x), "+v"(nb.y), "+v"(nb.z), "+v"(nb.w));  // keep the two paths apart (no flat_ loads)
+            } else
+#endif
+            {
+                na = nodes[2 * ref], nb = nodes[2 * ref + 1];
+            }
             if (STATS) cnt[RT_STAT_NODE] += 2;
             const float limit = any ? r.tmax : fminf(h.t, r.tmax);
             // per axis: plane distance t = (o + q*step)/d - origin/d = q * (step/d) + (o/d - origin/d)
@@ -477,7 +495,21 @@ __device__ __forceinline__ bool occluded(const KernelParams &P, const Ray &r, ui
     float t, b1, b2;
     if (MODE != MODE_BVH) {
         if (MODE == MODE_LDS) {
-            for (uint32_t i = 0; i < P.n_spheres; i++) occ |= hit_sphere(s_geom[i], r, i == self, t);
+            // as in closest_hit: a sphere whose discriminant is negative for every lane of the wave (nearly all of them for
+            // shadow rays, which run from a surface to the light) is dropped before the square root and the window tests
+            for (uint32_t i = 0; i < P.n_spheres; i++) {
+                const rt_f4 g = s_geom[i];
+                const f3 oc = mk3(r.o.x - g.x, r.o.y - g.y, r.o.z - g.z);
+                const float half_b = dot(oc, r.d);
+                float c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -g.w)));
+                c = (i == self) ? 0.0f : c;
+                const float disc = fmaf(half_b, half_b, -c);
+                if (__ballot(disc >= 0.0f) == 0ull) continue;
+                const float root = fast_sqrt(disc);
+                const float n0 = half_b + root, n1 = half_b - root;
+                const float tt = (n0 < -r.tmin) ? -n0 : -n1;  // hit_sphere
+                occ |= (n1 < -r.tmin) & (tt < r.tmax);
+            }
         } else {
             for (uint32_t i = 0; i < P.n_spheres; i++) occ |= hit_sphere(P.sph_geom[i], r, i == self, t);
         }
@@ -636,6 +668,14 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
     uint32_t *s_stack = (uint32_t *)(s_shade_mem + (MODE == MODE_LDS ? 3u * P.n_spheres : 0u));
     uint2 *s_pix_all = (uint2 *)(s_stack + (MODE == MODE_BVH ? P.bvh_levels * 256u : 0u));  // per pixel {RNG key, x | y << 16}
     float *s_L_all = (float *)(s_pix_all + 256);
+    // MODE_BVH: the staged top of the tree sits behind the ring and its row counters (rt_launch_render sizes it)
+    lds_u4 *s_top = (lds_u4 *)((uint32_t *)(s_L_all + 4u * 3u * (P.ring_rows << 6)) + 64);
+    const uint32_t n_top = (RT_BVH_TOP_NODES > 0 && MODE == MODE_BVH) ? P.bvh_top_nodes : 0u;
+    if (RT_BVH_TOP_NODES > 0 && MODE == MODE_BVH && n_top) {
+        const lds_u4 *src = (const lds_u4 *)P.bvh_nodes;
+        for (uint32_t i = threadIdx.x; i < 2u * n_top; i += 256) s_top[i] = src[i];
+        __syncthreads();
+    }
     const rt_f4 *s_geom = s_geom_mem;
     if (MODE == MODE_LDS) {
         const uint32_t n_padded = (P.n_spheres + RT_SCAN_UNROLL - 1u) & ~(RT_SCAN_UNROLL - 1u);
@@ -823,8 +863,8 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 }
                 if (tracing) {
                     bool blocked;
-                    if (LIGHTS) blocked = bvh_run<STATS, 2, true>(P, r, lit ? h.shape : self, h, bs, deep, cnt, s_stack, lit != 0u);
-                    else blocked = bvh_run<STATS, 0, true>(P, r, self, h, bs, deep, cnt, s_stack);
+                    if (LIGHTS) blocked = bvh_run<STATS, 2, true>(P, r, lit ? h.shape : self, h, bs, deep, cnt, s_stack, lit != 0u, s_top, n_top);
+                    else blocked = bvh_run<STATS, 0, true>(P, r, self, h, bs, deep, cnt, s_stack, false, s_top, n_top);
                     if (bs.ref != RT_BVH_DONE) return 2;  // parked: the finished lanes of the wave shade and fetch new work
                     tracing = false;
                     if (LIGHTS && lit) {  // the shadow ray of light lit - 1 has left the tree
@@ -1363,10 +1403,17 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
         uint32_t lds_levels = RT_BVH_LDS_LEVELS;
         if (const char *e = getenv("RTHIP_STACK_LDS")) lds_levels = uint32_t(atoi(e));  // tuning knob; results do not depend on it
         if (lds_levels < P.bvh_levels) P.bvh_levels = lds_levels;
-        lds = P.bvh_levels * 1024u + 2048u + 4u * 3u * 64u * 4u * P.ring_rows + 4u * 16u * 4u;
+        // RT_BVH_TOP_NODES > 0 (off by default: measured slower): that many nodes of the top of the tree in LDS, 32 B each
+        // (breadth-first prefix; knob RTHIP_BVH_TOP; results do not depend on it)
+        uint32_t top = RT_BVH_TOP_NODES;
+        if (const char *e = getenv("RTHIP_BVH_TOP")) top = RT_BVH_TOP_NODES > 0 ? uint32_t(atoi(e)) : 0u;
+        if (top > P.bvh_top_nodes) top = P.bvh_top_nodes;
+        P.bvh_top_nodes = top;
+        lds = P.bvh_levels * 1024u + 2048u + 4u * 3u * 64u * 4u * P.ring_rows + 4u * 16u * 4u + top * 32u;
     } else {
         P.ring_rows = 1;  // lane = pixel: no radiance slots
         P.bvh_levels = 0;
+        P.bvh_top_nodes = 0;
         lds = (mode == MODE_LDS) ? (RT_LDS_SPHERES + 3u * P.n_spheres) * 16u : 16u;
     }
     if (lds > 65536u) return hipErrorInvalidValue;

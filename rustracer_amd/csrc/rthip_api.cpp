@@ -428,6 +428,7 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
         uint32_t bvh_levels = 0;
         if (rt_wants_bvh(s->n_spheres, s->n_triangles)) bvh_levels = rt_build_bvh(s, nodes, prims);
         if (bvh_levels > RT_BVH_MAX_DEPTH) return fail(ctx, RTHIP_E_INTERNAL, "BVH deeper than the traversal stack");
+        const uint32_t bvh_top = rt_bvh_top_first(nodes, RT_BVH_TOP_MAX);
         std::vector<DevBvhNodeQ> qnodes;
         if (!rt_bvh_quantize(nodes, qnodes)) return fail(ctx, RTHIP_E_INTERNAL, "BVH node quantisation failed");
         if ((st = upload(ctx, ctx->bvh_nodes, qnodes.data(), qnodes.size() * sizeof(DevBvhNodeQ)))) return st;
@@ -453,6 +454,7 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
         k.n_lights = uint32_t(s->n_lights);
         k.n_bvh_nodes = uint32_t(nodes.size());
         k.bvh_levels = bvh_levels;
+        k.bvh_top_nodes = bvh_top;
         k.sph_geom = (const rt_f4 *)ctx->sph_geom.p, k.sph_shade = (const rt_f4 *)ctx->sph_shade.p;
         k.pln_geom = (const rt_f4 *)ctx->pln_geom.p, k.tri_geom = (const rt_f4 *)ctx->tri_geom.p;
         k.materials = (const DevMaterial *)ctx->materials.p;

@@ -149,6 +149,27 @@ int main(int argc, char **argv) {
                 return fail("quantised box 0 looser than one step", long(i), k);
         }
     }
+    // the device order: top of the tree first, breadth-first (the kernel stages a prefix of the array in LDS): still the same
+    // tree — every node reachable once, every leaf intact — a parent before its children inside the prefix, nothing behind the
+    // prefix pointing back into it
+    {
+        std::vector<DevBvhNode> re = nodes;
+        const uint32_t n_top = rt_bvh_top_first(re, RT_BVH_TOP_MAX);
+        if (n_top != std::min<size_t>(RT_BVH_TOP_MAX, re.size())) return fail("top-of-tree prefix size", long(n_top), long(re.size()));
+        if (re.size() != nodes.size()) return fail("reordered node count");
+        Checker c2{s, re, prims, std::vector<int>(re.size(), 0), std::vector<int>(prims.size(), 0)};
+        c2.visit(0, nullptr, nullptr, 0);
+        if (c2.errors) return fail("reordered tree fails the invariants");
+        for (size_t i = 0; i < re.size(); i++)
+            if (c2.node_refs[i] != 1) return fail("reordered: node not reachable exactly once", long(i), c2.node_refs[i]);
+        if (c2.max_levels != levels) return fail("reordered: depth changed", levels, c2.max_levels);
+        for (size_t pos = 0; pos < re.size(); pos++)
+            for (uint32_t ref : {re[pos].ref0, re[pos].ref1}) {
+                if (ref & RT_BVH_LEAF_BIT) continue;
+                if (pos < n_top && ref <= pos) return fail("reordered: child before its parent in the prefix", long(pos), long(ref));
+                if (pos >= n_top && ref < n_top) return fail("reordered: a node behind the prefix points into it", long(pos), long(ref));
+            }
+    }
     // FNV-1a over the node and primitive arrays: the threaded build must give the tree of the serial one
     uint64_t hsh = 1469598103934665603ull;
     auto mix = [&](const void *p, size_t bytes) {
