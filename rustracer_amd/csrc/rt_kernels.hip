@@ -46,6 +46,9 @@
 #ifndef RT_SCAN_PIN_NTMIN
 #define RT_SCAN_PIN_NTMIN 0
 #endif
+#ifndef RT_STATE_MOVES
+#define RT_STATE_MOVES 1
+#endif
 #ifndef RT_SCAN_TAKE_BALLOT
 #define RT_SCAN_TAKE_BALLOT 0
 #endif
@@ -957,8 +960,10 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     emit(T * c);
                     done = true;
                 } else {
-                    cosi = dot(r.d, sf.n);
-                    refl = fma3(sf.n, -2.0f * cosi, r.d);  // metal.rs:27-29, dielectric.rs:28-30 (unit incoming direction)
+                    if (LIGHTS) {  // the mirror direction feeds the Phong term; without lights next_ray() computes it, and only for Metal / Dielectric
+                        cosi = dot(r.d, sf.n);
+                        refl = fma3(sf.n, -2.0f * cosi, r.d);  // metal.rs:27-29, dielectric.rs:28-30 (unit incoming direction)
+                    }
                     if (LIGHTS && POOL && sf.kind != RTHIP_MAT_DIELECTRIC) {
                         // the work-pool variant traces its shadow rays like any other ray of the pool (resumable, together with the
                         // closest-hit rays of the other lanes); same terms in the same order as the loop below
@@ -1033,43 +1038,67 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 // (H/(W-1) and V/(H-1) are precomputed: P.hw*, P.vh*)
                 nd = mk3(fmaf(P.vhx, ub, fmaf(P.hwx, ua, pp.x)), fmaf(P.vhy, ub, fmaf(P.hwy, ua, pp.y)), fmaf(P.vhz, ub, fmaf(P.hwz, ua, pp.z)));
                 if (LIGHTS) Ld = mk3(0.0f, 0.0f, 0.0f);
+#if RT_STATE_MOVES
+                // the rest of the path state, reset IN PLACE ("+v": same register in and out, so the join needs no copies): plain
+                // moves under the branch's lane mask cost half of what selects on the mask do (tools/ubench: 2.3 vs 4.2 cycles)
+                asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.x) : "v"(cam_v.x));  // camera.rs:43-50
+                asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.y) : "v"(cam_v.y));
+                asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.z) : "v"(cam_v.z));
+                asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.x));
+                asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.y));
+                asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.z));
+                asm volatile("v_mov_b32 %0, 0" : "+v"(bounce));
+                asm volatile("v_mov_b32 %0, -1" : "+v"(self));  // RT_NONE
+#endif
             } else {
                 // random_unit_vector — lambertian_diffuse.rs:39-45, metal.rs:31-37 (a first, then z); v_sin/v_cos take revolutions
                 const float z = fmaf(2.0f, ub, -1.0f);
                 const float rr = fast_sqrt(fmaf(-z, z, 1.0f));
                 const f3 w = mk3(rr * __builtin_amdgcn_cosf(ua), rr * __builtin_amdgcn_sinf(ua), z);
-                // Lambertian: n + w (lambertian_diffuse.rs:68-73); Metal: reflect + fuzz*w (metal.rs:59-60): one shared unit vector
-                const bool lambert = sf.kind == RTHIP_MAT_LAMBERTIAN;
-                const f3 base = lambert ? sf.n : refl;
-                const float wf = lambert ? 1.0f : sf.param;
-                nd = fma3(w, wf, base);
-                // metal.rs:62-64: absorbed if the new direction points into the surface. Lambertian::bounce always returns a ray
-                // (lambertian_diffuse.rs:68-73), also when rounding puts n + w a hair below the surface
-                dead = !lambert && dot(nd, sf.n) < 0.0f;
-                if (sf.kind == RTHIP_MAT_DIELECTRIC) {  // dielectric.rs:68-98
-                    // dot_product = direction . normal with the UN-normalised direction; len() is the element count 3: dielectric.rs:74-83
-                    const float len = r.tmin * (1.0f / RT_T_MIN);  // |direction|
-                    const float dp = cosi * len;
-                    const bool inside = dp > 0.0f;
-                    const float eta = inside ? sf.param : sf.inv_ior;
-                    const float cosine = (inside ? sf.param * dp : -dp) * (1.0f / 3.0f);
-                    // outward_normal = inside ? -n : n, so unit . outward_normal = -|cosi|
-                    const float dt = -fabsf(cosi);
-                    const float kk = fmaf(-eta * eta, fmaf(-dt, dt, 1.0f), 1.0f);  // dielectric.rs:39
-                    const float om = 1.0f - cosine;
-                    const float om2 = om * om;
-                    const float prob = (kk < 0.0f) ? 1.0f : fmaf(1.0f - sf.r1, om2 * om2 * om, sf.r1);  // dielectric.rs:47-52,87-92
-                    // refracted = (unit - on*dt)*eta - on*sqrt(k)   (dielectric.rs:44); the coin is ua (dielectric.rs:94)
-                    const float sgn = inside ? -1.0f : 1.0f;
-                    const float cn = sgn * (-dt * eta - fast_sqrt(kk));
-                    const f3 refr = fma3(sf.n, cn, r.d * eta);
-                    nd = (prob > ua) ? refl : refr;
-                    dead = false;
+                // One shared unit vector, then a BRANCH on the material: most waves (the ground) hold Lambertian hits only and skip the
+                // mirror direction, the absorption test and the dielectric block altogether.
+                if (sf.kind == RTHIP_MAT_LAMBERTIAN) {
+                    // Lambertian::bounce always returns a ray (lambertian_diffuse.rs:68-73), also when rounding puts n + w a hair
+                    // below the surface
+                    nd = sf.n + w;
+                } else {
+                    if (!LIGHTS) {
+                        cosi = dot(r.d, sf.n);
+                        refl = fma3(sf.n, -2.0f * cosi, r.d);  // metal.rs:27-29, dielectric.rs:28-30 (unit incoming direction)
+                    }
+                    nd = fma3(w, sf.param, refl);  // Metal: reflect + fuzz*w (metal.rs:59-60)
+                    // metal.rs:62-64: absorbed if the new direction points into the surface
+                    dead = dot(nd, sf.n) < 0.0f;
+                    if (sf.kind == RTHIP_MAT_DIELECTRIC) {  // dielectric.rs:68-98
+                        // dot_product = direction . normal with the UN-normalised direction; len() is the element count 3: dielectric.rs:74-83
+                        const float len = r.tmin * (1.0f / RT_T_MIN);  // |direction|
+                        const float dp = cosi * len;
+                        const bool inside = dp > 0.0f;
+                        const float eta = inside ? sf.param : sf.inv_ior;
+                        const float cosine = (inside ? sf.param * dp : -dp) * (1.0f / 3.0f);
+                        // outward_normal = inside ? -n : n, so unit . outward_normal = -|cosi|
+                        const float dt = -fabsf(cosi);
+                        const float kk = fmaf(-eta * eta, fmaf(-dt, dt, 1.0f), 1.0f);  // dielectric.rs:39
+                        const float om = 1.0f - cosine;
+                        const float om2 = om * om;
+                        const float prob = (kk < 0.0f) ? 1.0f : fmaf(1.0f - sf.r1, om2 * om2 * om, sf.r1);  // dielectric.rs:47-52,87-92
+                        // refracted = (unit - on*dt)*eta - on*sqrt(k)   (dielectric.rs:44); the coin is ua (dielectric.rs:94)
+                        const float sgn = inside ? -1.0f : 1.0f;
+                        const float cn = sgn * (-dt * eta - fast_sqrt(kk));
+                        const f3 refr = fma3(sf.n, cn, r.d * eta);
+                        nd = (prob > ua) ? refl : refr;
+                        dead = false;
+                    }
                 }
+#if RT_STATE_MOVES
+                asm volatile("v_add_u32 %0, 1, %0" : "+v"(bounce));
+                asm volatile("v_mov_b32 %0, %1" : "+v"(self) : "v"(h.shape));  // the ray starts on the shape it hit (the hit point is in r.o already)
+#endif
             }
             // The rest of the path state as SELECTS in straight-line code, one v_cndmask each. Written as assignments inside the
             // two branches (or as C++ selects on the branch condition, which the compiler turns back into that) they become phi
             // copies on both sides of the join: ~25 moves per iteration. Hence the asm.
+#if !RT_STATE_MOVES
             const unsigned long long fm = __ballot(fresh);
             asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r.o.x) : "v"(cam_v.x), "s"(fm));  // camera.rs:43-50 | the hit point (already in r.o)
             asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r.o.y) : "v"(cam_v.y), "s"(fm));
@@ -1079,6 +1108,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             asm("v_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(T.z) : "s"(fm));
             bounce = fresh ? 0u : bounce + 1u;
             asm("v_cndmask_b32_e64 %0, %1, -1, %2" : "=v"(self) : "v"(h.shape), "s"(fm));  // RT_NONE | the shape the ray starts on
+#endif
             set_dir(nd);
         };
         if constexpr (!POOL) {

@@ -6,7 +6,7 @@
 #include <string>
 
 #define REP 64
-#define ITERS 512
+#define ITERS 4096
 
 #define KERNEL(NAME, DECL, BODY)                                                   \
     __global__ __launch_bounds__(256) void NAME(unsigned *out, unsigned seed) {  \
@@ -71,6 +71,21 @@ KERNEL(k_sub, FDECL, ASM8F("v_sub_f32 %0, %0, %1"))
 KERNEL(k_sub_sgpr, FDECL, ASM8F("v_subrev_f32 %0, s8, %0"))
 KERNEL(k_cos, FDECL, ASM8F("v_cos_f32 %0, %0"))
 KERNEL(k_cvt_i32, FDECL, ASM8F("v_cvt_i32_f32 %0, %0"))
+
+// ---- where does a select get slow? (round 2) ----
+// raw select throughput with the mask in an SGPR pair / in VCC through the VOP3 encoding
+KERNEL(k_cnd_sgpr_only, FDECL, ASM8F("v_cndmask_b32_e64 %0, %0, %1, s[20:21]"))
+KERNEL(k_cnd_vcc_e64, FDECL, ASM8F("v_cndmask_b32_e64 %0, %0, %1, vcc"))
+// a compare, nine independent FMAs, then the select that uses it (mask in VCC / in an SGPR pair): reported per group of 11
+KERNEL(k_cmp_far_vcc, FDECL, _Pragma("unroll") for (int k = 0; k < 8; k++) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(x[k]) : "v"(y), "v"(z) : "vcc");)
+KERNEL(k_cmp_far_sgpr, FDECL, _Pragma("unroll") for (int k = 0; k < 8; k++) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_cndmask_b32 %0, %0, %2, s[20:21]" : "+v"(x[k]) : "v"(y), "v"(z) : "s20", "s21");)
+KERNEL(k_fma_x10, FDECL, _Pragma("unroll") for (int k = 0; k < 8; k++) asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2" : "+v"(x[k]) : "v"(y), "v"(z));)
+// two compares combined on the scalar unit, then two selects (the tail of a sphere test): mask in VCC / kept in an SGPR pair: per group of 4 VALU
+KERNEL(k_and_2cnd_vcc, FDECL, _Pragma("unroll") for (int k = 0; k < 8; k += 2) asm volatile("v_cmp_lt_f32 s[22:23], %0, %2\n\tv_cmp_nlt_f32 vcc, %1, %3\n\ts_and_b64 vcc, s[22:23], vcc\n\tv_cndmask_b32 %0, %0, %3, vcc\n\tv_cndmask_b32 %1, %1, %2, vcc" : "+v"(x[k]), "+v"(x[k + 1]) : "v"(y), "v"(z) : "vcc", "s22", "s23");)
+KERNEL(k_and_2cnd_sgpr, FDECL, _Pragma("unroll") for (int k = 0; k < 8; k += 2) asm volatile("v_cmp_lt_f32 s[22:23], %0, %2\n\tv_cmp_nlt_f32 s[20:21], %1, %3\n\ts_and_b64 s[20:21], s[22:23], s[20:21]\n\tv_cndmask_b32 %0, %0, %3, s[20:21]\n\tv_cndmask_b32 %1, %1, %2, s[20:21]" : "+v"(x[k]), "+v"(x[k + 1]) : "v"(y), "v"(z) : "s20", "s21", "s22", "s23");)
+KERNEL(k_mov, FDECL, ASM8F("v_mov_b32 %0, %1"))
+KERNEL(k_fma_neg, FDECL, ASM8F("v_fma_f32 %0, %0, %1, -%2"))
+KERNEL(k_cmp_e64_neg, FDECL, _Pragma("unroll") for (int k = 0; k < 8; k++) asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, -%1" : "+v"(x[k]) : "v"(y), "v"(z) : "s20", "s21");)
 
 // packed fp32: x is a float2 pair per chain
 __global__ __launch_bounds__(256) void k_pk_fma(unsigned *out, unsigned seed) {
@@ -139,7 +154,10 @@ int main() {
         {"v_fma_f32 sgpr src", k_fma_sgpr}, {"v_sub_f32", k_sub}, {"v_subrev_f32 sgpr", k_sub_sgpr}, {"v_cos_f32", k_cos}, {"v_cvt_i32_f32", k_cvt_i32},
         {"v_mul_lo_u32", k_mul_lo}, {"v_mul_hi_u32", k_mul_hi}, {"v_mul_u32_u24", k_mul_u24}, {"v_mad_u32_u24", k_mad_u24}, {"v_mad_u64_u32", k_mad_u64_u32},
         {"v_xor_b32", k_xor}, {"v_lshrrev_b32", k_lshr}, {"v_add_u32", k_add_u32}, {"v_add3_u32", k_add3}, {"v_xad_u32", k_xad}, {"v_lshl_add_u32", k_lshl_add},
-        {"v_alignbit_b32", k_alignbit}, {"v_bfe_u32", k_bfe}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_perm_b32", k_perm}, {"v_and_or_b32", k_and_or}};
+        {"v_alignbit_b32", k_alignbit}, {"v_bfe_u32", k_bfe}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_perm_b32", k_perm}, {"v_and_or_b32", k_and_or},
+        {"v_cndmask e64 sgpr mask only", k_cnd_sgpr_only}, {"v_cndmask e64 vcc", k_cnd_vcc_e64}, {"cmp, 9 fma, cndmask vcc (11)", k_cmp_far_vcc},
+        {"cmp, 9 fma, cndmask sgpr (11)", k_cmp_far_sgpr}, {"11 fma", k_fma_x10}, {"2 cmp, s_and, 2 cndmask vcc (x4)", k_and_2cnd_vcc},
+        {"2 cmp, s_and, 2 cndmask sgpr (x4)", k_and_2cnd_sgpr}, {"v_mov_b32", k_mov}, {"v_fma_f32 neg src", k_fma_neg}, {"v_cmp e64 neg", k_cmp_e64_neg}};
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     const int blocks = cus * 8;  // 8 blocks x 4 waves = 32 waves/CU = 8 waves/SIMD
