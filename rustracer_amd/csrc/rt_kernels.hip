@@ -46,6 +46,9 @@
 #ifndef RT_SCAN_PIN_NTMIN
 #define RT_SCAN_PIN_NTMIN 0
 #endif
+#ifndef RT_JITTER_VGPR
+#define RT_JITTER_VGPR 1
+#endif
 #ifndef RT_STATE_MOVES
 #define RT_STATE_MOVES 1
 #endif
@@ -650,6 +653,9 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 // MODE_BVH needs resident waves to cover its node fetches (every visit is a dependent, divergent 32-byte fetch): its speed follows
 // the number of waves (measured on C4/C5: 4 -> 5 -> 6 -> 7 waves per SIMD = 1.00 / 1.11 / 1.18 / 1.21), so the kernel is held to
 // 72 VGPRs (20 dwords of spills, outside the traversal loop) and its LDS to 22 KB per workgroup (see rt_launch_render).
+#ifndef RT_PRIMARY_INLINE
+#define RT_PRIMARY_INLINE 1
+#endif
 #ifndef RT_SCAN_LIGHT_WAVES
 #define RT_SCAN_LIGHT_WAVES 5
 #endif
@@ -754,8 +760,16 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             pp_own = pp;
         }
         const f3 cam_o = mk3(P.ox, P.oy, P.oz);
-        f3 cam_v = cam_o;  // ... in vector registers: operand of the select in next_ray (the lane mask already takes the one scalar operand)
+        f3 cam_v = cam_o;  // ... in vector registers: operand of the moves in next_ray
         asm volatile("" : "+v"(cam_v.x), "+v"(cam_v.y), "+v"(cam_v.z));
+#if RT_JITTER_VGPR
+        // the jitter vectors in vector registers too: an FMA with a scalar-register operand issues at 4.1 cycles, with vector
+        // operands only at 2.4 (tools/ubench/valu_rates.hip), and every fresh sample does six of them
+        f3 hw_v = mk3(P.hwx, P.hwy, P.hwz), vh_v = mk3(P.vhx, P.vhy, P.vhz);
+        asm volatile("" : "+v"(hw_v.x), "+v"(hw_v.y), "+v"(hw_v.z), "+v"(vh_v.x), "+v"(vh_v.y), "+v"(vh_v.z));
+#else
+        const f3 hw_v = mk3(P.hwx, P.hwy, P.hwz), vh_v = mk3(P.vhx, P.vhy, P.vhz);
+#endif
         f3 acc = mk3(0.0f, 0.0f, 0.0f);
         // ---- state of the path this lane is tracing ----
         uint32_t item = 0;   // radiance slot of the work item: ring row << 6 | pixel
@@ -847,46 +861,9 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             T = T * sf.tm;  // scatter (as at the end of shade())
             return 0;
         };
-        auto shade = [&]() -> int {
+        // Second part of shade(): the surface of the hit in `h` (or the sky), once the scene query has returned.
+        auto surface = [&]() -> int {
             bool done;
-            if (dead) {  // None -> new_color alone, ray.rs:80
-                dead = false;
-                emit(T);
-                return 1;
-            }
-            if (MODE == MODE_BVH) {
-                if (!tracing) {
-                    h.shape = RT_NONE;
-                    if (bounce != P.max_depth) {  // ray.rs:70-72: depth exhausted -> sky without a scene query
-                        h = closest_hit_unbounded<STATS>(P, r, cnt);
-                        bvh_begin(r, bs);
-                        tracing = true;
-                        cnt[RT_STAT_RAYS]++;
-                    }
-                }
-                if (tracing) {
-                    bool blocked;
-                    if (LIGHTS) blocked = bvh_run<STATS, 2, true>(P, r, lit ? h.shape : self, h, bs, deep, cnt, s_stack, lit != 0u, s_top, n_top);
-                    else blocked = bvh_run<STATS, 0, true>(P, r, self, h, bs, deep, cnt, s_stack, false, s_top, n_top);
-                    if (bs.ref != RT_BVH_DONE) return 2;  // parked: the finished lanes of the wave shade and fetch new work
-                    tracing = false;
-                    if (LIGHTS && lit) {  // the shadow ray of light lit - 1 has left the tree
-                        if (!blocked) {
-                            const DevMaterial m = P.materials[sf.mat];
-                            const DevLight lt = P.lights[lit - 1u];
-                            lsum = lsum + mk3(m.ar * lt.ir, m.ag * lt.ig, m.ab * lt.ib) * lsc;
-                        }
-                        lit++;
-                        return next_light();
-                    }
-                }
-            } else {
-                h.shape = RT_NONE;
-                if (bounce != P.max_depth) {  // ray.rs:70-72: depth exhausted -> sky without a scene query
-                    h = closest_hit<STATS, MODE>(P, r, self, cnt, s_stack, s_geom);
-                    cnt[RT_STAT_RAYS]++;
-                }
-            }
             if (h.shape == RT_NONE) {  // ray.rs:85, background_color ray.rs:89-93 (the direction is already unit)
                 // t = 0.5(d.y + 1); (1-t)(1,1,1) + t(0.5,0.7,1) = (1 - 0.5t, 1 - 0.3t, 1) = (0.75 - 0.25 d.y, 0.85 - 0.15 d.y, 1)
                 emit(mk3(T.x * fmaf(-0.25f, r.d.y, 0.75f), T.y * fmaf(-0.15f, r.d.y, 0.85f), T.z));
@@ -1007,6 +984,47 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             }
             return done ? 1 : 0;
         };
+        auto shade = [&]() -> int {
+            if (dead) {  // None -> new_color alone, ray.rs:80
+                dead = false;
+                emit(T);
+                return 1;
+            }
+            if (MODE == MODE_BVH) {
+                if (!tracing) {
+                    h.shape = RT_NONE;
+                    if (bounce != P.max_depth) {  // ray.rs:70-72: depth exhausted -> sky without a scene query
+                        h = closest_hit_unbounded<STATS>(P, r, cnt);
+                        bvh_begin(r, bs);
+                        tracing = true;
+                        cnt[RT_STAT_RAYS]++;
+                    }
+                }
+                if (tracing) {
+                    bool blocked;
+                    if (LIGHTS) blocked = bvh_run<STATS, 2, true>(P, r, lit ? h.shape : self, h, bs, deep, cnt, s_stack, lit != 0u, s_top, n_top);
+                    else blocked = bvh_run<STATS, 0, true>(P, r, self, h, bs, deep, cnt, s_stack, false, s_top, n_top);
+                    if (bs.ref != RT_BVH_DONE) return 2;  // parked: the finished lanes of the wave shade and fetch new work
+                    tracing = false;
+                    if (LIGHTS && lit) {  // the shadow ray of light lit - 1 has left the tree
+                        if (!blocked) {
+                            const DevMaterial m = P.materials[sf.mat];
+                            const DevLight lt = P.lights[lit - 1u];
+                            lsum = lsum + mk3(m.ar * lt.ir, m.ag * lt.ig, m.ab * lt.ib) * lsc;
+                        }
+                        lit++;
+                        return next_light();
+                    }
+                }
+            } else {
+                h.shape = RT_NONE;
+                if (bounce != P.max_depth) {  // ray.rs:70-72: depth exhausted -> sky without a scene query
+                    h = closest_hit<STATS, MODE>(P, r, self, cnt, s_stack, s_geom);
+                    cnt[RT_STAT_RAYS]++;
+                }
+            }
+            return surface();
+        };
         // Second half: the lane's next ray — the scattered ray of the surface shade() left behind, or
         // (fresh) the primary ray of a new sample. Both need one RNG pair and one normalisation; sharing
         // them halves that cost in a wave where some lanes continue and the others start a new path.
@@ -1036,7 +1054,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             if (fresh) {
                 // lib.rs:282-285 (x jitter first): u = (x + xi)/(W-1) = x/(W-1) + xi/(W-1), the per-pixel part is precomputed
                 // (H/(W-1) and V/(H-1) are precomputed: P.hw*, P.vh*)
-                nd = mk3(fmaf(P.vhx, ub, fmaf(P.hwx, ua, pp.x)), fmaf(P.vhy, ub, fmaf(P.hwy, ua, pp.y)), fmaf(P.vhz, ub, fmaf(P.hwz, ua, pp.z)));
+                nd = mk3(fmaf(vh_v.x, ub, fmaf(hw_v.x, ua, pp.x)), fmaf(vh_v.y, ub, fmaf(hw_v.y, ua, pp.y)), fmaf(vh_v.z, ub, fmaf(hw_v.z, ua, pp.z)));
                 if (LIGHTS) Ld = mk3(0.0f, 0.0f, 0.0f);
 #if RT_STATE_MOVES
                 // the rest of the path state, reset IN PLACE ("+v": same register in and out, so the join needs no copies): plain
@@ -1119,6 +1137,9 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             // square's corners with a factor pi/2 to spare, the right-hand side carries a relative margin 1e-4 (FP32: ~1e-6).
             // The fast loop below evaluates exactly the expressions of next_ray(fresh) + shade() for a miss: same bits.
             bool tile_empty = false;
+            // ... and per sphere: bit i of pmask = some primary ray of this wave can reach sphere i (wave-uniform; spheres 0..63)
+            unsigned long long pmask = ~0ull;
+            bool primary_inline = false;
             if (!STATS && !LIGHTS && MODE == MODE_LDS && P.n_planes == 0 && P.n_tris == 0 && P.max_depth != 0) {
                 const f3 hw = mk3(P.hwx, P.hwy, P.hwz), vh = mk3(P.vhx, P.vhy, P.vhz);
                 const f3 e00 = mk3(pp_own.x, pp_own.y, pp_own.z), e10 = e00 + hw, e01 = e00 + vh, e11 = e10 + vh;
@@ -1129,7 +1150,9 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 const float dev = fast_sqrt(fmaxf(fmaxf(dot(d0, d0), dot(d1, d1)), fmaxf(dot(d2, d2), dot(d3, d3))));
                 const float lmin = fast_sqrt(fminf(fminf(dot(e00, e00), dot(e10, e10)), fminf(dot(e01, e01), dot(e11, e11))));
                 const float theta = 1.6f * dev * fast_rcp(lmin);  // >= the angle between a and any ray of the bundle (sin x >= 2x/pi)
-                bool can_hit = !(theta < 0.5f);                   // a degenerate camera (NaN, huge pixels): no fast path
+                const bool degenerate = !(theta < 0.5f);          // a degenerate camera (NaN, huge pixels): no fast path
+                bool can_hit = degenerate;
+                unsigned long long pm = 0ull;
                 for (uint32_t i = 0; i < P.n_spheres; i++) {
                     const rt_f4 g = s_geom[i];
                     const f3 q = mk3(g.x - cam_o.x, g.y - cam_o.y, g.z - cam_o.z);
@@ -1137,9 +1160,14 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     const f3 qa = cross(q, a);
                     const float dist = (dot(q, a) >= 0.0f) ? fast_sqrt(dot(qa, qa)) : lq;
                     const float reach = fmaf(lq + rad, theta, rad) * 1.0001f + 1e-30f;
-                    can_hit |= !(dist > reach);  // NaN => can hit
+                    const bool ch = degenerate | !(dist > reach);  // NaN => can hit
+                    can_hit |= ch;
+                    if (RT_PRIMARY_INLINE && i < 64u && __ballot(active && ch) != 0ull) pm |= 1ull << i;
                 }
                 tile_empty = __ballot(active && can_hit) == 0ull;
+                pmask = pm;
+                // worth it where paths are short: the wave's primary rays see few of the spheres (the ground, mostly)
+                primary_inline = RT_PRIMARY_INLINE && !tile_empty && P.n_spheres <= 64u && 2u * uint32_t(__popcll(pm)) <= P.n_spheres;
             }
             if (tile_empty) {
                 if (active) {
@@ -1162,6 +1190,59 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     acc = acc + grp;
                     cnt[RT_STAT_PATHS] += n_spp;
                     cnt[RT_STAT_RAYS] += n_spp;
+                }
+            } else if (RT_PRIMARY_INLINE && primary_inline) {
+                // ---- lane = pixel, primary ray inline: a fresh sample traces its primary ray at once, against the spheres of pmask
+                // only, and joins the other lanes' scattered rays in the same iteration. Where most paths are "ground, then sky"
+                // a path then costs one full scan instead of two. The skipped spheres cannot be hit (the cone test above), the
+                // others are tested in index order with the expressions of closest_hit(): same hit, same bits.
+                if (active) {
+                    uint32_t s_done = 0;
+                    const uint32_t g_mask = P.slice_spp - 1u;
+                    const __attribute__((address_space(3))) lds_f4 *geom_lds = (const __attribute__((address_space(3))) lds_f4 *)s_geom;
+                    bool fresh = true;
+                    for (;;) {
+                        bool ended = false;
+                        if (fresh) {
+                            next_ray(true, lane, 0);
+                            float nbest = -__uint_as_float(__float_as_uint(r.tmax) - 1u);
+                            const float ntmin = -r.tmin;
+                            h.shape = RT_NONE;
+                            for (unsigned long long m = pmask; m != 0ull; m &= m - 1ull) {
+                                const uint32_t i = uint32_t(__builtin_ctzll(m));  // wave-uniform: broadcast read
+                                const lds_f4 gv = geom_lds[i];
+                                const f3 oc = mk3(r.o.x - gv.x, r.o.y - gv.y, r.o.z - gv.z);
+                                const float half_b = dot(oc, r.d);
+                                const float c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -gv.w)));
+                                const float disc = fmaf(half_b, half_b, -c);
+                                const float root = fast_sqrt(disc);
+                                const float n0 = half_b + root, n1 = half_b - root;
+                                const float n = (n0 < ntmin) ? n0 : n1;
+                                const bool take = (n1 < ntmin) & !(n < nbest);
+                                nbest = take ? n : nbest;
+                                h.shape = take ? i : h.shape;
+                            }
+                            h.t = -nbest;
+                            cnt[RT_STAT_RAYS]++;
+                            ended = surface() != 0;
+                        }
+                        if (!ended) {
+                            next_ray(false, 0, 0);
+                            fresh = shade() != 0;
+                        } else {
+                            fresh = true;
+                        }
+                        if (fresh) {
+                            s_done++;
+                            if (s_done == n_spp) break;
+                            if ((s_done & g_mask) == 0u) {
+                                acc = acc + grp;
+                                grp = mk3(0.0f, 0.0f, 0.0f);
+                            }
+                        }
+                    }
+                    acc = acc + grp;
+                    cnt[RT_STAT_PATHS] += s_done;
                 }
             } else
             // ---- lane = pixel: path regeneration over the pixel's samples ----
