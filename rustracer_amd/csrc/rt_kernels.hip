@@ -27,6 +27,7 @@
 //     its normalisation with the primary ray of a lane that starts a new sample (shade / next_ray);
 //   * radiance is handed over where a path ends (emit), not through a merged return value.
 // No MFMA: there is no dense contraction anywhere on this path.
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -387,7 +388,8 @@ __device__ __forceinline__ HitRec closest_hit_unbounded(const KernelParams &P, c
     return h;
 }
 
-template <bool STATS, int MODE>
+// SPH: the caller knows that the scene holds spheres only (no plane, no triangle): their (empty) loops are left out
+template <bool STATS, int MODE, bool SPH = false>
 __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &r, uint32_t self, uint32_t *cnt, uint32_t *s_stack,
                                               const rt_f4 *s_geom) {
     HitRec h;
@@ -455,6 +457,7 @@ __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &
             RT_TAKE(ok, t, i, (void)0)
         }
     }
+    if (SPH) return h;
     for (uint32_t i = 0; i < P.n_planes; i++) {
         float t;
         bool ok = hit_plane(P.pln_geom[4 * i], r, t);
@@ -656,6 +659,7 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 #ifndef RT_PRIMARY_INLINE
 #define RT_PRIMARY_INLINE 1
 #endif
+#define RT_PRIMARY_SPHERES 64u /* the primary-inline loop keeps one reachability bit per sphere */
 #ifndef RT_SCAN_LIGHT_WAVES
 #define RT_SCAN_LIGHT_WAVES 5
 #endif
@@ -693,6 +697,13 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             // plane or triangle (their shape ids follow the spheres'), which replaces c by 0 — a NaN half_b keeps the discriminant NaN
             s_geom_mem[i] = i < P.n_spheres ? P.sph_geom[i] : rt_f4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), -__builtin_inff()};
         for (uint32_t i = threadIdx.x; i < 3 * P.n_spheres; i += 256) s_shade_mem[i] = P.sph_shade[i];
+        if (RT_PRIMARY_INLINE && threadIdx.x < RT_PRIMARY_SPHERES && threadIdx.x < P.n_spheres) {
+            // what a sphere test needs of a ray's origin, for the camera (every primary ray starts there): o - c and |o - c|^2 - r^2,
+            // with the very expressions of closest_hit() — the primary-inline loop reads them instead of recomputing them per ray
+            const rt_f4 g = P.sph_geom[threadIdx.x];
+            const f3 oc = mk3(P.ox - g.x, P.oy - g.y, P.oz - g.z);
+            s_shade_mem[3 * P.n_spheres + threadIdx.x] = rt_f4{oc.x, oc.y, oc.z, fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -g.w)))};
+        }
         __syncthreads();
     }
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -740,6 +751,9 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
     uint32_t cnt[RT_STAT_N];
 #pragma unroll
     for (int i = 0; i < RT_STAT_N; i++) cnt[i] = 0;
+#ifdef RT_CLASS_CYCLES
+    uint32_t dbg_shard = 255u;  // debug: counters filed per reachability mask of the wave (255 = sky-only / other loops)
+#endif
 
     if (amask != 0ull) {
         uint2 *s_pix = s_pix_all + (wave << 6);
@@ -862,17 +876,22 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             return 0;
         };
         // Second part of shade(): the surface of the hit in `h` (or the sky), once the scene query has returned.
-        auto surface = [&]() -> int {
+        // (sph: a compile-time flag — the scene holds spheres only)
+        // prim: the ray is a primary ray, so T = 1 and the origin is the camera: x * 1.0f = x exactly, so T is left out)
+        auto surface = [&](auto sph, auto prim) -> int {
+            constexpr bool SPH = decltype(sph)::value;
+            constexpr bool PRIM = decltype(prim)::value;
             bool done;
             if (h.shape == RT_NONE) {  // ray.rs:85, background_color ray.rs:89-93 (the direction is already unit)
                 // t = 0.5(d.y + 1); (1-t)(1,1,1) + t(0.5,0.7,1) = (1 - 0.5t, 1 - 0.3t, 1) = (0.75 - 0.25 d.y, 0.85 - 0.15 d.y, 1)
-                emit(mk3(T.x * fmaf(-0.25f, r.d.y, 0.75f), T.y * fmaf(-0.15f, r.d.y, 0.85f), T.z));
+                if (PRIM) emit(mk3(fmaf(-0.25f, r.d.y, 0.75f), fmaf(-0.15f, r.d.y, 0.85f), 1.0f));
+                else emit(mk3(T.x * fmaf(-0.25f, r.d.y, 0.75f), T.y * fmaf(-0.15f, r.d.y, 0.85f), T.z));
                 done = true;
                 if (STATS) cnt[RT_STAT_SKY]++;
             } else {
-                r.o = fma3(r.d, h.t, r.o);  // ray.rs:30-32: the hit point p (an alias of r.o, see above)
+                r.o = fma3(r.d, h.t, PRIM ? cam_v : r.o);  // ray.rs:30-32: the hit point p (an alias of r.o, see above)
                 // ---- the surface: normal + material (collision.rs:29-43) ----
-                if (h.shape < P.n_spheres) {
+                if (SPH || h.shape < P.n_spheres) {
                     rt_f4 r0, r1, r2;
                     if constexpr (MODE == MODE_LDS) {  // kept apart so that the LDS reads stay ds_read_b128 (no generic pointer)
                         const rt_f4 *rec = (const rt_f4 *)((const unsigned char *)s_shade_mem + __umul24(h.shape, 48u));  // 32-bit address math
@@ -917,7 +936,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 if (sf.kind == RTHIP_MAT_TEXTURE) {
                     // Texture::scatter — texture.rs:45-57; bounce -> None (texture.rs:59-61) => path ends, ray.rs:80
                     float U, V;
-                    if (h.shape < P.n_spheres) {
+                    if (SPH || h.shape < P.n_spheres) {
                         U = (1.0f + atan2_finite(sf.tu, sf.tv) * 0.31830988618379067f) * 0.5f;  // sphere.rs:70
                         V = acosf(sf.tw) * 0.31830988618379067f;                          // sphere.rs:71
                     } else if (h.shape < P.n_spheres + P.n_planes) {
@@ -934,7 +953,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     const uint32_t tyl = texture_wrap(V, sf.param, ti.height, ti.magic_h);
                     const uint32_t texel = P.texels[ti.first_texel + (((tyl >> 3) * ti.tiles_per_row + (txl >> 3)) << 6) + ((tyl & 7u) << 3) + (txl & 7u)];
                     const f3 c = mk3(float(texel & 255u), float((texel >> 8) & 255u), float((texel >> 16) & 255u)) * (1.0f / 255.0f);
-                    emit(T * c);
+                    emit(PRIM ? c : T * c);
                     done = true;
                 } else {
                     if (LIGHTS) {  // the mirror direction feeds the Phong term; without lights next_ray() computes it, and only for Metal / Dielectric
@@ -978,13 +997,14 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                         }
                         Ld = Ld + T * sum;
                     }
-                    T = T * sf.tm;  // scatter: albedo/pi * 3 (lambertian_diffuse.rs:53-66, metal.rs:45-56, dielectric.rs:56-66)
+                    T = PRIM ? sf.tm : T * sf.tm;  // scatter: albedo/pi * 3 (lambertian_diffuse.rs:53-66, metal.rs:45-56, dielectric.rs:56-66)
                     done = false;
                 }
             }
             return done ? 1 : 0;
         };
-        auto shade = [&]() -> int {
+        auto shade = [&](auto sph) -> int {
+            constexpr bool SPH = decltype(sph)::value;
             if (dead) {  // None -> new_color alone, ray.rs:80
                 dead = false;
                 emit(T);
@@ -1019,16 +1039,18 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             } else {
                 h.shape = RT_NONE;
                 if (bounce != P.max_depth) {  // ray.rs:70-72: depth exhausted -> sky without a scene query
-                    h = closest_hit<STATS, MODE>(P, r, self, cnt, s_stack, s_geom);
+                    h = closest_hit<STATS, MODE, SPH>(P, r, self, cnt, s_stack, s_geom);
                     cnt[RT_STAT_RAYS]++;
                 }
             }
-            return surface();
+            return surface(sph, std::integral_constant<bool, false>{});
         };
         // Second half: the lane's next ray — the scattered ray of the surface shade() left behind, or
         // (fresh) the primary ray of a new sample. Both need one RNG pair and one normalisation; sharing
         // them halves that cost in a wave where some lanes continue and the others start a new path.
         uint32_t key_own = rt_counter(__float_as_uint(pp_own.w), P.sample0 + s_first, 0);  // !POOL: slot 0 of this pixel's next sample
+        constexpr std::integral_constant<bool, true> sph_only{};
+        constexpr std::integral_constant<bool, false> any_shape{};
         auto next_ray = [&](bool fresh, uint32_t pixel, uint32_t sample) {
             rt_f4 pp = pp_own;
             uint32_t k = key + RT_RNG_GOLDEN;  // RNG slot 1 + bounce
@@ -1169,6 +1191,11 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 // worth it where paths are short: the wave's primary rays see few of the spheres (the ground, mostly)
                 primary_inline = RT_PRIMARY_INLINE && !tile_empty && P.n_spheres <= 64u && 2u * uint32_t(__popcll(pm)) <= P.n_spheres;
             }
+#ifdef RT_CLASS_CYCLES  // debug build: wall-clock ticks (100 MHz) and waves per tile class, in the hit / test counters
+            const unsigned long long t_class0 = wall_clock64();
+            const uint32_t tile_class = tile_empty ? 0u : (primary_inline ? 1u : 2u);
+            dbg_shard = tile_empty ? 255u : (uint32_t(pmask) & 15u) | (primary_inline ? 0u : 16u);
+#endif
             if (tile_empty) {
                 if (active) {
                     const uint32_t g_mask = P.slice_spp - 1u;
@@ -1199,22 +1226,35 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 if (active) {
                     uint32_t s_done = 0;
                     const uint32_t g_mask = P.slice_spp - 1u;
-                    const __attribute__((address_space(3))) lds_f4 *geom_lds = (const __attribute__((address_space(3))) lds_f4 *)s_geom;
+                    const __attribute__((address_space(3))) lds_f4 *prim_lds = (const __attribute__((address_space(3))) lds_f4 *)(s_shade_mem + 3u * P.n_spheres);
                     bool fresh = true;
                     for (;;) {
                         bool ended = false;
+#ifdef RT_CLASS_CYCLES
+                        {
+                            const unsigned long long ex = __ballot(true);
+                            if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex), 0u)) == 0) cnt[RT_STAT_NODE] += 64;
+                            cnt[RT_STAT_SKY]++;
+                            cnt[RT_STAT_SHADOW] += fresh ? 1u : 0u;
+                        }
+#endif
                         if (fresh) {
-                            next_ray(true, lane, 0);
+                            // next_ray(true) without the state a primary ray does not need (origin = camera, T = 1, no shape to start on)
+                            key = key_own;
+                            key_own += RT_RNG_SLOTS * RT_RNG_GOLDEN;
+                            const uint32_t hb = rt_mix32(key);
+                            const float ua = rt_unit(hb), ub = rt_unit(rt_second(hb));
+                            set_dir(mk3(fmaf(vh_v.x, ub, fmaf(hw_v.x, ua, pp_own.x)), fmaf(vh_v.y, ub, fmaf(hw_v.y, ua, pp_own.y)),
+                                        fmaf(vh_v.z, ub, fmaf(hw_v.z, ua, pp_own.z))));
+                            asm volatile("v_mov_b32 %0, 0" : "+v"(bounce));
                             float nbest = -__uint_as_float(__float_as_uint(r.tmax) - 1u);
                             const float ntmin = -r.tmin;
                             h.shape = RT_NONE;
                             for (unsigned long long m = pmask; m != 0ull; m &= m - 1ull) {
                                 const uint32_t i = uint32_t(__builtin_ctzll(m));  // wave-uniform: broadcast read
-                                const lds_f4 gv = geom_lds[i];
-                                const f3 oc = mk3(r.o.x - gv.x, r.o.y - gv.y, r.o.z - gv.z);
-                                const float half_b = dot(oc, r.d);
-                                const float c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -gv.w)));
-                                const float disc = fmaf(half_b, half_b, -c);
+                                const lds_f4 pv = prim_lds[i];                    // {camera - centre, |camera - centre|^2 - r^2}
+                                const float half_b = dot(mk3(pv.x, pv.y, pv.z), r.d);
+                                const float disc = fmaf(half_b, half_b, -pv.w);
                                 const float root = fast_sqrt(disc);
                                 const float n0 = half_b + root, n1 = half_b - root;
                                 const float n = (n0 < ntmin) ? n0 : n1;
@@ -1224,11 +1264,14 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                             }
                             h.t = -nbest;
                             cnt[RT_STAT_RAYS]++;
-                            ended = surface() != 0;
+                            ended = surface(sph_only, std::integral_constant<bool, true>{}) != 0;
+#ifdef RT_CLASS_CYCLES
+                            cnt[RT_STAT_HIT0 + 3] += ended ? 1u : 0u;
+#endif
                         }
                         if (!ended) {
                             next_ray(false, 0, 0);
-                            fresh = shade() != 0;
+                            fresh = shade(sph_only) != 0;
                         } else {
                             fresh = true;
                         }
@@ -1257,7 +1300,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                         if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex), 0u)) == 0) cnt[RT_STAT_SHADOW] += 64;
                     }
 #endif
-                    const bool fresh = shade() != 0;
+                    const bool fresh = shade(any_shape) != 0;
                     if (fresh) {
                         s_done++;
                         if (s_done == n_spp) break;
@@ -1271,6 +1314,12 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 acc = acc + grp;
                 cnt[RT_STAT_PATHS] += s_done;
             }
+#ifdef RT_CLASS_CYCLES
+            if (lane == 0u) {
+                cnt[RT_STAT_HIT0 + tile_class] += uint32_t(wall_clock64() - t_class0);
+                cnt[RT_STAT_SPHERE + tile_class] += 1u;
+            }
+#endif
         } else {
             // Work items in hand-out order: item i = (pixel i & 63, sample i >> 6). The radiance of sample row r waits in ring
             // slot r & (rows - 1); the oldest row is retired (added to the pixels' sums, in sample order) as soon as its last
@@ -1315,7 +1364,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 }
                 next = min(next + uint32_t(__popcll(need)), limit);
                 if (have) {
-                    const int st = shade();
+                    const int st = shade(any_shape);
                     if (st == 1) {
                         cnt[RT_STAT_PATHS]++;
                         have = false;
@@ -1343,11 +1392,17 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
     if (!P.stats) return;
 #pragma unroll
     for (int i = 0; i < RT_STAT_N; i++) {
+#ifndef RT_CLASS_CYCLES
         if (!STATS && i > RT_STAT_RAYS && i < RT_STAT_PIX_TRACED) continue;
+#endif
         uint32_t v = cnt[i];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+#ifdef RT_CLASS_CYCLES
+        if (lane == 0 && v) atomicAdd(&P.stats[dbg_shard * RT_STAT_N + i], (unsigned long long)v);
+#else
         if (lane == 0 && v) atomicAdd(&P.stats[((blockIdx.x * 4u + wave) & (RT_STAT_SHARDS - 1)) * RT_STAT_N + i], (unsigned long long)v);
+#endif
     }
 }
 
@@ -1525,7 +1580,7 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
         P.ring_rows = 1;  // lane = pixel: no radiance slots
         P.bvh_levels = 0;
         P.bvh_top_nodes = 0;
-        lds = (mode == MODE_LDS) ? (RT_LDS_SPHERES + 3u * P.n_spheres) * 16u : 16u;
+        lds = (mode == MODE_LDS) ? (RT_LDS_SPHERES + 3u * P.n_spheres + RT_PRIMARY_SPHERES) * 16u : 16u;
     }
     if (lds > 65536u) return hipErrorInvalidValue;
     if (P.n_slices == 0 || P.slice_spp == 0 || (P.n_slices > 1 && (uint64_t(P.n_slices) * P.slice_spp < P.spp || !P.partial))) return hipErrorInvalidValue;

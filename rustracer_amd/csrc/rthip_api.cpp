@@ -182,6 +182,10 @@ const char *rthip_status_string(int status) {
     }
 }
 
+#ifdef RT_CLASS_CYCLES
+// debug build (tools/class_cycles.py): the raw counter shards of the last pass — the kernel files its counters under shard = pmask
+extern "C" const unsigned long long *rthip_debug_shards(rthip_ctx *ctx) { return ctx->stats_host; }
+#endif
 double rthip_algorithmic_flops(const rthip_stats *s) {
     if (!s) return 0.0;
     const double hits = double(s->hits[0]) + double(s->hits[1]) + double(s->hits[2]) + double(s->hits[3]);
