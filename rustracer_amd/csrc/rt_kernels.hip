@@ -1162,7 +1162,8 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             // ... and per sphere: bit i of pmask = some primary ray of this wave can reach sphere i (wave-uniform; spheres 0..63)
             unsigned long long pmask = ~0ull;
             bool primary_inline = false;
-            if (!STATS && !LIGHTS && MODE == MODE_LDS && P.n_planes == 0 && P.n_tris == 0 && P.max_depth != 0) {
+            // (point lights change neither: a primary ray that reaches no shape gathers no light, and the cone test is about primary rays)
+            if (!STATS && MODE == MODE_LDS && P.n_planes == 0 && P.n_tris == 0 && P.max_depth != 0) {
                 const f3 hw = mk3(P.hwx, P.hwy, P.hwz), vh = mk3(P.vhx, P.vhy, P.vhz);
                 const f3 e00 = mk3(pp_own.x, pp_own.y, pp_own.z), e10 = e00 + hw, e01 = e00 + vh, e11 = e10 + vh;
                 const f3 ec = e00 + (hw + vh) * 0.5f;
@@ -1247,6 +1248,15 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                             set_dir(mk3(fmaf(vh_v.x, ub, fmaf(hw_v.x, ua, pp_own.x)), fmaf(vh_v.y, ub, fmaf(hw_v.y, ua, pp_own.y)),
                                         fmaf(vh_v.z, ub, fmaf(hw_v.z, ua, pp_own.z))));
                             asm volatile("v_mov_b32 %0, 0" : "+v"(bounce));
+                            if (LIGHTS) {  // the direct-light code of surface() reads T and the origin: no shortcut for them
+                                Ld = mk3(0.0f, 0.0f, 0.0f);
+                                asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.x) : "v"(cam_v.x));
+                                asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.y) : "v"(cam_v.y));
+                                asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.z) : "v"(cam_v.z));
+                                asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.x));
+                                asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.y));
+                                asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.z));
+                            }
                             float nbest = -__uint_as_float(__float_as_uint(r.tmax) - 1u);
                             const float ntmin = -r.tmin;
                             h.shape = RT_NONE;
@@ -1264,7 +1274,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                             }
                             h.t = -nbest;
                             cnt[RT_STAT_RAYS]++;
-                            ended = surface(sph_only, std::integral_constant<bool, true>{}) != 0;
+                            ended = surface(sph_only, std::integral_constant<bool, !LIGHTS>{}) != 0;
 #ifdef RT_CLASS_CYCLES
                             cnt[RT_STAT_HIT0 + 3] += ended ? 1u : 0u;
 #endif

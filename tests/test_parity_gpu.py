@@ -595,3 +595,38 @@ def test_empty_tile_fast_path_is_exact(standalone_flat):
         n_sky_only += int(b.stats["rays"] == b.stats["paths"])
     assert n_sky_only < 24   # the scenes do put spheres in view
     rt.close()
+
+
+@pytest.mark.parametrize("lights", [False, True])
+def test_primary_inline_loop_is_exact(standalone_flat, lights):
+    """Waves whose primary rays can reach at most half of the spheres trace the primary ray inline, against those spheres
+    only (per-sphere cone test), and the sky-only waves skip the scene altogether — with and without point lights. The
+    instrumented kernel has neither loop: same bits, same ray counts. Scenes: the standalone frame, and random scenes of
+    up to 70 spheres of all four materials (more than 64 spheres: the loop must step aside) over a ground sphere."""
+    from rustracer_amd import Metal, Dielectric, PointLight
+    fl = abi.F_POINT_LIGHTS if lights else 0
+    flat = flatten(presets.standalone_scene(), presets.standalone_lights()) if lights else standalone_flat
+    rt = Raytracer.new(1920, 1080, seed=14)
+    a = rt.render(flat, 5, max_depth=5, flags=fl)
+    b = rt.render(flat, 5, max_depth=5, flags=fl | abi.F_COUNT_STATS)
+    assert np.array_equal(a.accum, b.accum) and np.array_equal(a.rgba8, b.rgba8)
+    assert a.stats["rays"] == b.stats["rays"] and a.stats["paths"] == b.stats["paths"]
+    rt.close()
+    rng = np.random.default_rng(15)
+    rt = Raytracer.new(640, 360, seed=16)
+    tex = presets.standalone_scene()[3].material
+    for trial in range(12):
+        n = int(rng.choice([2, 3, 7, 20, 63, 70]))
+        scene = [Sphere.new((0.0, -100.5, -1.0), 100.0, Lambertian.new_from_hex(0x007070))]
+        for _ in range(n):
+            c = rng.uniform(-3, 3, 3) * np.array([1.0, 0.3, 1.0]) + np.array([0.0, 0.0, -2.0])
+            kind = int(rng.integers(0, 4))
+            mat = (Lambertian.new(rng.uniform(0.1, 0.9, 3)), Metal.new(rng.uniform(0.3, 0.9, 3), float(rng.uniform(0, 0.5))),
+                   Dielectric.new((1.0, 0.9, 0.9), 1.3), tex)[kind]
+            scene.append(Sphere.new(c, float(rng.choice([0.05, 0.2, 0.5])), mat))
+        flat = flatten(scene, [PointLight((3.0, 4.0, 2.0), (20.0, 20.0, 20.0))] if lights else ())
+        a = rt.render(flat, 3, max_depth=6, flags=fl)
+        b = rt.render(flat, 3, max_depth=6, flags=fl | abi.F_COUNT_STATS)
+        assert np.array_equal(a.accum, b.accum), f"trial {trial} ({n} spheres): {(a.accum != b.accum).any(axis=2).sum()} pixels differ"
+        assert a.stats["rays"] == b.stats["rays"] and a.stats["paths"] == b.stats["paths"]
+    rt.close()
