@@ -656,6 +656,16 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 // MODE_BVH needs resident waves to cover its node fetches (every visit is a dependent, divergent 32-byte fetch): its speed follows
 // the number of waves (measured on C4/C5: 4 -> 5 -> 6 -> 7 waves per SIMD = 1.00 / 1.11 / 1.18 / 1.21), so the kernel is held to
 // 72 VGPRs (20 dwords of spills, outside the traversal loop) and its LDS to 22 KB per workgroup (see rt_launch_render).
+#ifdef RT_ARM_COUNTS  // debug build (with RT_CLASS_CYCLES): how often a divergent arm runs (x 64) and for how many lanes
+#define RT_ARM_COUNT(slot_execs, slot_lanes)                                                                                    \
+    {                                                                                                                           \
+        const unsigned long long ex_ = __ballot(true);                                                                          \
+        if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex_ >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex_), 0u)) == 0) cnt[slot_execs] += 64; \
+        cnt[slot_lanes]++;                                                                                                      \
+    }
+#else
+#define RT_ARM_COUNT(slot_execs, slot_lanes)
+#endif
 #ifndef RT_PRIMARY_INLINE
 #define RT_PRIMARY_INLINE 1
 #endif
@@ -935,6 +945,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 }
                 if (sf.kind == RTHIP_MAT_TEXTURE) {
                     // Texture::scatter — texture.rs:45-57; bounce -> None (texture.rs:59-61) => path ends, ray.rs:80
+                    RT_ARM_COUNT(2, 3)
                     float U, V;
                     if (SPH || h.shape < P.n_spheres) {
                         U = (1.0f + atan2_finite(sf.tu, sf.tv) * 0.31830988618379067f) * 0.5f;  // sphere.rs:70
@@ -1102,6 +1113,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     // below the surface
                     nd = sf.n + w;
                 } else {
+                    RT_ARM_COUNT(7, 8)
                     if (!LIGHTS) {
                         cosi = dot(r.d, sf.n);
                         refl = fma3(sf.n, -2.0f * cosi, r.d);  // metal.rs:27-29, dielectric.rs:28-30 (unit incoming direction)
@@ -1110,6 +1122,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     // metal.rs:62-64: absorbed if the new direction points into the surface
                     dead = dot(nd, sf.n) < 0.0f;
                     if (sf.kind == RTHIP_MAT_DIELECTRIC) {  // dielectric.rs:68-98
+                        RT_ARM_COUNT(4, 6)
                         // dot_product = direction . normal with the UN-normalised direction; len() is the element count 3: dielectric.rs:74-83
                         const float len = r.tmin * (1.0f / RT_T_MIN);  // |direction|
                         const float dp = cosi * len;
@@ -1325,10 +1338,12 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 cnt[RT_STAT_PATHS] += s_done;
             }
 #ifdef RT_CLASS_CYCLES
+#ifndef RT_ARM_COUNTS
             if (lane == 0u) {
                 cnt[RT_STAT_HIT0 + tile_class] += uint32_t(wall_clock64() - t_class0);
                 cnt[RT_STAT_SPHERE + tile_class] += 1u;
             }
+#endif
 #endif
         } else {
             // Work items in hand-out order: item i = (pixel i & 63, sample i >> 6). The radiance of sample row r waits in ring

@@ -15,18 +15,20 @@ flat = flatten(presets.standalone_scene())
 libs = [(p, load(p)) for p in sys.argv[1:]]
 W, H = 3840, 2160
 spp = int(os.environ.get("SPP", "64")); depth = int(os.environ.get("DEPTH", "5"))
+TARGET = tuple(float(v) for v in os.environ["TARGET"].split(",")) if os.environ.get("TARGET") else (0.0, 0.0, -1.0)  # camera target
 ctxs = []
 for name, l in libs:
     ctx = C.c_void_p(); assert l.rthip_create(0, C.byref(ctx)) == 0
     assert l.rthip_upload_scene(ctx, C.byref(flat.desc)) == 0
-    cam = abi.Camera(); l.rthip_camera_lookat(-1.8, 1.0, 2.0, (C.c_double*3)(0,0,-1), C.byref(cam)); l.rthip_set_camera(ctx, C.byref(cam))
+    cam = abi.Camera(); l.rthip_camera_lookat(-1.8, 1.0, 2.0, (C.c_double*3)(*TARGET), C.byref(cam)); l.rthip_set_camera(ctx, C.byref(cam))
     ctxs.append(ctx)
+BAND = tuple(int(v) for v in os.environ["BAND"].split(",")) if os.environ.get("BAND") else (0, 0, 1)
 out = np.zeros((H, W, 4), np.uint8)
 ref = None
 REP = int(os.environ.get("REP", "4"))  # back-to-back launches per library and round: the clocks stay up, the minimum is reported
 for rnd in range(3):
     for (name, l), ctx in zip(libs, ctxs):
-        p = make_params(W, H, spp, depth, rnd)
+        p = make_params(W, H, spp, depth, rnd, 0, *BAND)  # BAND="rows,first,stride": only that band of rows (e.g. ground-only tiles)
         st = abi.Stats()
         times = []
         for _ in range(REP):

@@ -27,6 +27,16 @@ l.rthip_debug_shards.restype = C.POINTER(C.c_ulonglong)
 l.rthip_debug_shards.argtypes = [C.c_void_p]
 sh = l.rthip_debug_shards(ctx)
 N = 14  # RT_STAT_N: 0 paths, 1 rays, 2-4 waves per class, 5 wave iterations x 64, 6-8 ticks per class, 9 ended at primary, 10 lane iterations, 11 fresh
+if os.environ.get("ARMS"):  # -DRT_ARM_COUNTS build: slots 2-4, 6-8 count the divergent arms instead
+    print("pmask: wave iterations; per wave iteration: texture arm runs / lanes in it, dielectric arm, non-Lambertian scatter arm")
+    for m in list(range(32)):
+        r = [sh[m * N + i] for i in range(N)]
+        if not r[5]:
+            continue
+        wi = r[5] / 64
+        print(f"  {m & 15:04b}: wave iterations {wi:12.0f}  texture {r[2] / 64 / wi:.3f} runs, {r[3] / max(r[2] / 64, 1):5.1f} lanes/run | dielectric {r[4] / 64 / wi:.3f} runs, "
+              f"{r[6] / max(r[4] / 64, 1):5.1f} lanes/run | non-Lambertian {r[7] / 64 / wi:.3f} runs, {r[8] / max(r[7] / 64, 1):5.1f} lanes/run")
+    sys.exit(0)
 print("pmask(+16 = general loop): waves, share of ticks, us/wave, paths, rays/path, wave iterations/wave, lane occupancy, fresh share")
 for m in list(range(32)) + [255]:
     r = [sh[m * N + i] for i in range(N)]
