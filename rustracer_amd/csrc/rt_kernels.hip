@@ -789,8 +789,9 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
 #if RT_JITTER_VGPR
         // the jitter vectors in vector registers too: an FMA with a scalar-register operand issues at 4.1 cycles, with vector
         // operands only at 2.4 (tools/ubench/valu_rates.hip), and every fresh sample does six of them
+        // (not in the BVH kernel: it is short of registers, and a path there is hundreds of instructions per jitter)
         f3 hw_v = mk3(P.hwx, P.hwy, P.hwz), vh_v = mk3(P.vhx, P.vhy, P.vhz);
-        asm volatile("" : "+v"(hw_v.x), "+v"(hw_v.y), "+v"(hw_v.z), "+v"(vh_v.x), "+v"(vh_v.y), "+v"(vh_v.z));
+        if (!POOL) asm volatile("" : "+v"(hw_v.x), "+v"(hw_v.y), "+v"(hw_v.z), "+v"(vh_v.x), "+v"(vh_v.y), "+v"(vh_v.z));
 #else
         const f3 hw_v = mk3(P.hwx, P.hwy, P.hwz), vh_v = mk3(P.vhx, P.vhy, P.vhz);
 #endif
