@@ -585,6 +585,22 @@ __device__ __forceinline__ float atan2_finite(float y, float x) {
     a = x < 0.0f ? 3.14159274f - a : a;
     return __builtin_copysignf(a, y);
 }
+// acos(x) / pi (sphere.rs:71) = sqrt(1 - |x|) * P(|x|), mirrored for x < 0: Abramowitz & Stegun 4.4.46 (|error| <= 2e-8 in exact
+// arithmetic) with the coefficients divided by pi. In FP32 its largest error over [-1, 1] is 8.9e-8, the device library's acosf
+// followed by the multiply 1.05e-7 (2 000 001 points against double) — at 13 instructions instead of 22. |x| > 1 (a rounded
+// (p - c).y / r) gives NaN like acosf, which the texture wrap's cast turns into texel row 0 like Rust's `as i32`.
+__device__ __forceinline__ float acos_over_pi(float x) {
+    const float t = fabsf(x);
+    float q = fmaf(t, -0x1.a56262p-12f, 0x1.164948p-9f);
+    q = fmaf(t, q, -0x1.6478a2p-8f);
+    q = fmaf(t, q, 0x1.4236cap-7f);
+    q = fmaf(t, q, -0x1.05ab22p-6f);
+    q = fmaf(t, q, 0x1.d00ad2p-6f);
+    q = fmaf(t, q, -0x1.17cb18p-4f);
+    q = fmaf(t, q, 0.5f);
+    const float v = fast_sqrt(1.0f - t) * q;
+    return x < 0.0f ? 1.0f - v : v;
+}
 
 // what shading needs to know about the surface that was hit
 struct Surface {
@@ -950,7 +966,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     float U, V;
                     if (SPH || h.shape < P.n_spheres) {
                         U = (1.0f + atan2_finite(sf.tu, sf.tv) * 0.31830988618379067f) * 0.5f;  // sphere.rs:70
-                        V = acosf(sf.tw) * 0.31830988618379067f;                          // sphere.rs:71
+                        V = acos_over_pi(sf.tw);                                             // sphere.rs:71
                     } else if (h.shape < P.n_spheres + P.n_planes) {
                         const uint32_t i = h.shape - P.n_spheres;
                         const rt_f4 g1 = P.pln_geom[4 * i + 1], g2 = P.pln_geom[4 * i + 2], g3 = P.pln_geom[4 * i + 3];
