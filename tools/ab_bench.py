@@ -11,7 +11,11 @@ def load(path):
         fn = getattr(l, name); fn.restype = res; fn.argtypes = args
     return l
 
-flat = flatten(presets.standalone_scene())
+scene = presets.standalone_scene()
+if os.environ.get("NOTEX"):  # the texture sphere becomes Lambertian: what of the HBM fetch traffic is the texture?
+    from rustracer_amd import Lambertian
+    scene[3] = type(scene[3]).new(scene[3].center, scene[3].radius, Lambertian.new_from_hex(0x707000))
+flat = flatten(scene)
 libs = [(p, load(p)) for p in sys.argv[1:]]
 W, H = 3840, 2160
 spp = int(os.environ.get("SPP", "64")); depth = int(os.environ.get("DEPTH", "5"))
