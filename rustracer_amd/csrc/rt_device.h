@@ -3,7 +3,7 @@
 //
 // HBM layout (all arrays 16-byte aligned, read-only during a render):
 //   sph_geom  [n_spheres] float4 {cx, cy, cz, r*r}          -> the closest-hit scan reads ONLY this
-//   sph_shade [n_spheres] 3 x float4 {c, 1/r} {albedo/pi*3, param} {kind, r1, 1/ior, material}: the merged
+//   sph_shade [n_spheres] 4 x float4 {c, 1/r} {albedo/pi*3, param} {kind, r1 | texture index, 1/ior, material} {albedo/pi, shininess}: the merged
 //             sphere+material shading record, read once per hit by the hitting lane
 //   (scenes of <= RT_LDS_SPHERES spheres: both arrays are staged in LDS once per workgroup)
 //   pln_geom  [n_planes]  2 x float4 {nx,ny,nz, n.p0} {mat(bits), 0,0,0} + tangent frame 2 x float4
@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #define RT_LDS_SPHERES 256u
+#define RT_SHADE_RECS 4u  // float4 records per sphere in sph_shade (64 B: the record address is a shift)
 #define RT_RING_ROWS 4u  // MODE_BVH: sample rows in a wave's radiance ring
 // samples per slice: 64, doubled until at most 16 slices cover spp; a function of spp alone, always a power of two
 #ifndef RT_SLICE_SPP
@@ -42,7 +43,7 @@ struct DevMaterial {
     uint32_t kind;         // RTHIP_MAT_*
     uint32_t texture;      // texture index
     float shininess;       // ext: Phong exponent
-    float r1;              // DIELECTRIC: ((1-ior)/(1+ior))^2   dielectric.rs:48-49
+    float r1;              // DIELECTRIC: ((1-ior)/(1+ior))^2   dielectric.rs:48-49 | TEXTURE: the texture index, as bits
     float ar, ag, ab;      // albedo/pi (direct-light term of the point-light extension)
     float inv_ior;         // DIELECTRIC: 1/ior  dielectric.rs:81
 };

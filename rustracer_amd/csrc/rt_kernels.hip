@@ -612,6 +612,8 @@ struct Surface {
     uint32_t kind;     // RTHIP_MAT_*
     uint32_t mat;      // material index (texture / light terms are fetched from DevMaterial when needed)
     float tu, tv, tw;  // sphere: (p-c).z, (p-c).x, (p-c).y/r for the texture coordinates (sphere.rs:67-73)
+    f3 la;             // point-light extension, scan modes: albedo/pi (the direct-light term) ...
+    float shin;        // ... and the Phong exponent
 };
 
 // The end of generate_pixel for one pixel — lib.rs:289-313: add the prior running sum, store it, tonemap, and (adaptive)
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
     extern __shared__ __align__(16) unsigned char s_dyn[];
     rt_f4 *s_geom_mem = (rt_f4 *)s_dyn;
     rt_f4 *s_shade_mem = s_geom_mem + (MODE == MODE_LDS ? RT_LDS_SPHERES : 0u);  // fixed offsets: folded into the ds_read offset field
-    uint32_t *s_stack = (uint32_t *)(s_shade_mem + (MODE == MODE_LDS ? 3u * P.n_spheres : 0u));
+    uint32_t *s_stack = (uint32_t *)(s_shade_mem + (MODE == MODE_LDS ? RT_SHADE_RECS * P.n_spheres : 0u));
     uint2 *s_pix_all = (uint2 *)(s_stack + (MODE == MODE_BVH ? P.bvh_levels * 256u : 0u));  // per pixel {RNG key, x | y << 16}
     float *s_L_all = (float *)(s_pix_all + 256);
     // MODE_BVH: the staged top of the tree sits behind the ring and its row counters (rt_launch_render sizes it)
@@ -722,13 +724,13 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             // padding: never hit. The centre is NaN, not just r*r = -inf: a padding index can equal `self` when the ray starts on a
             // plane or triangle (their shape ids follow the spheres'), which replaces c by 0 — a NaN half_b keeps the discriminant NaN
             s_geom_mem[i] = i < P.n_spheres ? P.sph_geom[i] : rt_f4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), -__builtin_inff()};
-        for (uint32_t i = threadIdx.x; i < 3 * P.n_spheres; i += 256) s_shade_mem[i] = P.sph_shade[i];
+        for (uint32_t i = threadIdx.x; i < RT_SHADE_RECS * P.n_spheres; i += 256) s_shade_mem[i] = P.sph_shade[i];
         if (RT_PRIMARY_INLINE && threadIdx.x < RT_PRIMARY_SPHERES && threadIdx.x < P.n_spheres) {
             // what a sphere test needs of a ray's origin, for the camera (every primary ray starts there): o - c and |o - c|^2 - r^2,
             // with the very expressions of closest_hit() — the primary-inline loop reads them instead of recomputing them per ray
             const rt_f4 g = P.sph_geom[threadIdx.x];
             const f3 oc = mk3(P.ox - g.x, P.oy - g.y, P.oz - g.z);
-            s_shade_mem[3 * P.n_spheres + threadIdx.x] = rt_f4{oc.x, oc.y, oc.z, fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -g.w)))};
+            s_shade_mem[RT_SHADE_RECS * P.n_spheres + threadIdx.x] = rt_f4{oc.x, oc.y, oc.z, fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -g.w)))};
         }
         __syncthreads();
     }
@@ -842,6 +844,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
         f3 refl = mk3(0.0f, 0.0f, 0.0f);
         float cosi = 0.0f;
         Surface sf;
+        sf.la = mk3(0.0f, 0.0f, 0.0f), sf.shin = 0.0f;
         sf.n = sf.tm = mk3(0.0f, 0.0f, 0.0f), sf.param = sf.r1 = sf.inv_ior = sf.tu = sf.tv = sf.tw = 0.0f, sf.kind = sf.mat = 0;
         bool dead = false;  // the last scatter absorbed the path (metal.rs:62-64): it ends, with L = T, at the next shade()
         // First half of a segment: closest hit and shading. Returns 1 = the path ended with radiance L,
@@ -919,16 +922,18 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 r.o = fma3(r.d, h.t, PRIM ? cam_v : r.o);  // ray.rs:30-32: the hit point p (an alias of r.o, see above)
                 // ---- the surface: normal + material (collision.rs:29-43) ----
                 if (SPH || h.shape < P.n_spheres) {
-                    rt_f4 r0, r1, r2;
+                    rt_f4 r0, r1, r2, rec_light = rt_f4{0.0f, 0.0f, 0.0f, 0.0f};
                     if constexpr (MODE == MODE_LDS) {  // kept apart so that the LDS reads stay ds_read_b128 (no generic pointer)
-                        const rt_f4 *rec = (const rt_f4 *)((const unsigned char *)s_shade_mem + __umul24(h.shape, 48u));  // 32-bit address math
+                        const rt_f4 *rec = (const rt_f4 *)((const unsigned char *)s_shade_mem + (h.shape << 6));  // 32-bit address math, RT_SHADE_RECS * 16 B
                         r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                        if (LIGHTS && !POOL) rec_light = rec[3];
                         // pin the loaded values: otherwise the loads are sunk to their uses and merged with the
                         // material loads of the non-sphere branch into per-dword flat loads
                         asm volatile("" : "+v"(r1.x), "+v"(r1.y), "+v"(r1.z), "+v"(r1.w), "+v"(r2.x), "+v"(r2.y), "+v"(r2.z), "+v"(r2.w));
                     } else {
-                        const rt_f4 *rec = P.sph_shade + 3 * h.shape;
+                        const rt_f4 *rec = P.sph_shade + RT_SHADE_RECS * h.shape;
                         r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                        if (LIGHTS && !POOL) rec_light = rec[3];
                     }
                     const f3 pc = mk3(p.x - r0.x, p.y - r0.y, p.z - r0.z);
                     sf.n = pc * r0.w;  // (p - c)/r
@@ -939,6 +944,10 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     sf.inv_ior = r2.z;
                     sf.mat = __float_as_uint(r2.w);
                     sf.tu = pc.z, sf.tv = pc.x, sf.tw = pc.y * r0.w;
+                    if (LIGHTS && !POOL) {  // the fourth record: read where the others are (LDS), not from the material table
+                        const rt_f4 r3 = rec_light;
+                        sf.la = mk3(r3.x, r3.y, r3.z), sf.shin = r3.w;
+                    }
                 } else {
                     if (h.shape < P.n_spheres + P.n_planes) {
                         const uint32_t i = h.shape - P.n_spheres;
@@ -954,6 +963,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     const DevMaterial m = P.materials[sf.mat];
                     sf.tm = mk3(m.tr, m.tg, m.tb);
                     sf.param = m.param, sf.kind = m.kind, sf.r1 = m.r1, sf.inv_ior = m.inv_ior;
+                    if (LIGHTS && !POOL) sf.la = mk3(m.ar, m.ag, m.ab), sf.shin = m.shininess;
                     // (sf.tu/tv/tw keep whatever an earlier sphere hit left: only sphere textures read them)
                 }
                 if (STATS) {
@@ -976,7 +986,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     } else {
                         U = h.b1, V = h.b2;
                     }
-                    const DevTexInfo ti = P.tex_info[P.materials[sf.mat].texture];
+                    const DevTexInfo ti = P.tex_info[__float_as_uint(sf.r1)];  // a texture material's r1 slot holds its texture index
                     const uint32_t txl = texture_wrap(U, sf.param, ti.width, ti.magic_w);
                     const uint32_t tyl = texture_wrap(V, sf.param, ti.height, ti.magic_h);
                     const uint32_t texel = P.texels[ti.first_texel + (((tyl >> 3) * ti.tiles_per_row + (txl >> 3)) << 6) + ((tyl & 7u) << 3) + (txl & 7u)];
@@ -997,7 +1007,6 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     }
                     if (LIGHTS && !POOL && sf.kind != RTHIP_MAT_DIELECTRIC) {
                         // extension (RTHIP_F_POINT_LIGHTS): Lambert N.L on Lambertian, Phong (R.L)^s on Metal, one shadow ray per light
-                        const DevMaterial m = P.materials[sf.mat];
                         f3 sum = mk3(0.0f, 0.0f, 0.0f);
                         for (uint32_t li = 0; li < P.n_lights; li++) {
                             const DevLight lt = P.lights[li];
@@ -1009,7 +1018,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                             if (sf.kind == RTHIP_MAT_LAMBERTIAN)
                                 w = fmaxf(0.0f, dot(sf.n, ldir));
                             else
-                                w = (m.shininess > 0.0f) ? __powf(fmaxf(0.0f, dot(refl, ldir)), m.shininess) : 0.0f;
+                                w = (sf.shin > 0.0f) ? __powf(fmaxf(0.0f, dot(refl, ldir)), sf.shin) : 0.0f;
                             if (w > 0.0f) {
                                 cnt[RT_STAT_RAYS]++;
                                 if (STATS) cnt[RT_STAT_SHADOW]++;
@@ -1019,7 +1028,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                                 sr.tmin = RT_T_MIN * dist, sr.tmax = dist;
                                 if (!occluded<STATS, MODE>(P, sr, h.shape, cnt, s_stack, s_geom)) {
                                     const float sc = w * fast_rcp(dist2);
-                                    sum = sum + mk3(m.ar * lt.ir, m.ag * lt.ig, m.ab * lt.ib) * sc;
+                                    sum = sum + mk3(sf.la.x * lt.ir, sf.la.y * lt.ig, sf.la.z * lt.ib) * sc;
                                 }
                             }
                         }
@@ -1257,7 +1266,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 if (active) {
                     uint32_t s_done = 0;
                     const uint32_t g_mask = P.slice_spp - 1u;
-                    const __attribute__((address_space(3))) lds_f4 *prim_lds = (const __attribute__((address_space(3))) lds_f4 *)(s_shade_mem + 3u * P.n_spheres);
+                    const __attribute__((address_space(3))) lds_f4 *prim_lds = (const __attribute__((address_space(3))) lds_f4 *)(s_shade_mem + RT_SHADE_RECS * P.n_spheres);
                     bool fresh = true;
                     for (;;) {
                         bool ended = false;
@@ -1622,7 +1631,7 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
         P.ring_rows = 1;  // lane = pixel: no radiance slots
         P.bvh_levels = 0;
         P.bvh_top_nodes = 0;
-        lds = (mode == MODE_LDS) ? (RT_LDS_SPHERES + 3u * P.n_spheres + RT_PRIMARY_SPHERES) * 16u : 16u;
+        lds = (mode == MODE_LDS) ? (RT_LDS_SPHERES + RT_SHADE_RECS * P.n_spheres + RT_PRIMARY_SPHERES) * 16u : 16u;
     }
     if (lds > 65536u) return hipErrorInvalidValue;
     if (P.n_slices == 0 || P.slice_spp == 0 || (P.n_slices > 1 && (uint64_t(P.n_slices) * P.slice_spp < P.spp || !P.partial))) return hipErrorInvalidValue;

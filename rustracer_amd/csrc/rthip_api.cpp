@@ -351,17 +351,22 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
                 d.r1 = float(r0 * r0);
                 d.inv_ior = float(1.0 / m.param);  // dielectric.rs:81
             }
+            // the Schlick term is a dielectric's alone: for a texture material the slot carries the texture index (as bits), so that
+            // the texture arm of the kernel finds it in the surface record it already holds instead of loading the material again
+            if (m.kind == RTHIP_MAT_TEXTURE) d.r1 = bits_f(m.texture);
         }
         if ((st = upload(ctx, ctx->materials, mats.data(), mats.size() * sizeof(DevMaterial)))) return st;
-        // ---- spheres: geom {c, r^2}; shading record 3 x float4 {c, 1/r} {albedo/pi*3, param} {kind, r1, 1/ior, material} ----
-        std::vector<rt_f4> geom(s->n_spheres), shade(3 * s->n_spheres);
+        // ---- spheres: geom {c, r^2}; shading record 4 x float4 {c, 1/r} {albedo/pi*3, param} {kind, r1 | texture, 1/ior, material}
+        //      {albedo/pi, shininess} (the last one is read by the point-light code only) ----
+        std::vector<rt_f4> geom(s->n_spheres), shade(RT_SHADE_RECS * s->n_spheres);
         for (uint64_t i = 0; i < s->n_spheres; i++) {
             const rthip_sphere &sp = s->spheres[i];
             const DevMaterial &m = mats[sp.material];
             geom[i] = f4(sp.center[0], sp.center[1], sp.center[2], sp.radius * sp.radius);
-            shade[3 * i + 0] = f4(sp.center[0], sp.center[1], sp.center[2], 1.0 / sp.radius);
-            shade[3 * i + 1] = rt_f4{m.tr, m.tg, m.tb, m.param};
-            shade[3 * i + 2] = rt_f4{bits_f(m.kind), m.r1, m.inv_ior, bits_f(sp.material)};
+            shade[RT_SHADE_RECS * i + 0] = f4(sp.center[0], sp.center[1], sp.center[2], 1.0 / sp.radius);
+            shade[RT_SHADE_RECS * i + 1] = rt_f4{m.tr, m.tg, m.tb, m.param};
+            shade[RT_SHADE_RECS * i + 2] = rt_f4{bits_f(m.kind), m.r1, m.inv_ior, bits_f(sp.material)};
+            shade[RT_SHADE_RECS * i + 3] = rt_f4{m.ar, m.ag, m.ab, m.shininess};
         }
         if ((st = upload(ctx, ctx->sph_geom, geom.data(), geom.size() * sizeof(rt_f4)))) return st;
         if ((st = upload(ctx, ctx->sph_shade, shade.data(), shade.size() * sizeof(rt_f4)))) return st;
