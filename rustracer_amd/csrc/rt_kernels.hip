@@ -41,21 +41,6 @@
 #ifndef RT_SCAN_UNROLL
 #define RT_SCAN_UNROLL 4u  /* MODE_LDS: spheres per group of the closest-hit scan; divides RT_LDS_SPHERES */
 #endif
-#ifndef RT_SCAN_PRELOAD
-#define RT_SCAN_PRELOAD 0
-#endif
-#ifndef RT_SCAN_PIN_NTMIN
-#define RT_SCAN_PIN_NTMIN 0
-#endif
-#ifndef RT_JITTER_VGPR
-#define RT_JITTER_VGPR 1
-#endif
-#ifndef RT_STATE_MOVES
-#define RT_STATE_MOVES 1
-#endif
-#ifndef RT_SCAN_TAKE_BALLOT
-#define RT_SCAN_TAKE_BALLOT 0
-#endif
 
 enum { MODE_LDS = 0, MODE_BVH = 1, MODE_GLOBAL = 2 };
 
@@ -400,9 +385,6 @@ __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &
         // tracked negated: nbest = -h.t, starting just above -tmax, so "not (n < nbest)" <=> t <= best < tmax
         float nbest = -h.t;
         float ntmin = -r.tmin;
-#if RT_SCAN_PIN_NTMIN
-        asm volatile("" : "+v"(ntmin));  // a register holding -tmin: the compares stay in the short VOPC encoding (no source modifier)
-#endif
         // The staged array is padded to a multiple of RT_SCAN_UNROLL with spheres that cannot be hit (NaN centre: the discriminant
         // is NaN), so the loop runs in groups of RT_SCAN_UNROLL with constant LDS offsets and constant indices (one address
         // register per group instead of an address and an index move per sphere; the group's broadcast reads issue together).
@@ -412,22 +394,10 @@ __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &
             uint32_t grp_addr = uint32_t(size_t((const __attribute__((address_space(3))) rt_f4 *)s_geom)) + base * 16u;
             asm volatile("" : "+v"(grp_addr));
             const __attribute__((address_space(3))) lds_f4 *grp_geom = (const __attribute__((address_space(3))) lds_f4 *)uintptr_t(grp_addr);
-#if RT_SCAN_PRELOAD
-            lds_f4 pre[RT_SCAN_UNROLL];  // the group's reads issue together, ahead of the first test
-#pragma unroll
-            for (uint32_t k = 0; k < RT_SCAN_UNROLL; k++) {
-                pre[k] = grp_geom[k];
-                asm volatile("" : "+v"(pre[k]));
-            }
-#endif
 #pragma unroll
             for (uint32_t k = 0; k < RT_SCAN_UNROLL; k++) {
                 const uint32_t i = base + k;
-#if RT_SCAN_PRELOAD
-                const lds_f4 gv = pre[k];
-#else
                 const lds_f4 gv = grp_geom[k];  // one ds_read_b128 (16-byte aligned vector type)
-#endif
                 const rt_f4 g = rt_f4{gv.x, gv.y, gv.z, gv.w};
                 const f3 oc = mk3(r.o.x - g.x, r.o.y - g.y, r.o.z - g.z);
                 const float half_b = dot(oc, r.d);
@@ -442,9 +412,6 @@ __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &
                 const float n0 = half_b + root, n1 = half_b - root;
                 const float n = (n0 < ntmin) ? n0 : n1;
                 const bool take = (n1 < ntmin) & !(n < nbest);
-#if RT_SCAN_TAKE_BALLOT
-                if (__ballot(take) == 0ull) continue;  // nobody's closest hit changes: skip the two selects
-#endif
                 nbest = take ? n : nbest;
                 h.shape = take ? i : h.shape;
             }
@@ -804,15 +771,11 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
         const f3 cam_o = mk3(P.ox, P.oy, P.oz);
         f3 cam_v = cam_o;  // ... in vector registers: operand of the moves in next_ray
         asm volatile("" : "+v"(cam_v.x), "+v"(cam_v.y), "+v"(cam_v.z));
-#if RT_JITTER_VGPR
         // the jitter vectors in vector registers too: an FMA with a scalar-register operand issues at 4.1 cycles, with vector
         // operands only at 2.4 (tools/ubench/valu_rates.hip), and every fresh sample does six of them
         // (not in the BVH kernel: it is short of registers, and a path there is hundreds of instructions per jitter)
         f3 hw_v = mk3(P.hwx, P.hwy, P.hwz), vh_v = mk3(P.vhx, P.vhy, P.vhz);
         if (!POOL) asm volatile("" : "+v"(hw_v.x), "+v"(hw_v.y), "+v"(hw_v.z), "+v"(vh_v.x), "+v"(vh_v.y), "+v"(vh_v.z));
-#else
-        const f3 hw_v = mk3(P.hwx, P.hwy, P.hwz), vh_v = mk3(P.vhx, P.vhy, P.vhz);
-#endif
         f3 acc = mk3(0.0f, 0.0f, 0.0f);
         // ---- state of the path this lane is tracing ----
         uint32_t item = 0;   // radiance slot of the work item: ring row << 6 | pixel
@@ -1115,7 +1078,6 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 // (H/(W-1) and V/(H-1) are precomputed: P.hw*, P.vh*)
                 nd = mk3(fmaf(vh_v.x, ub, fmaf(hw_v.x, ua, pp.x)), fmaf(vh_v.y, ub, fmaf(hw_v.y, ua, pp.y)), fmaf(vh_v.z, ub, fmaf(hw_v.z, ua, pp.z)));
                 if (LIGHTS) Ld = mk3(0.0f, 0.0f, 0.0f);
-#if RT_STATE_MOVES
                 // the rest of the path state, reset IN PLACE ("+v": same register in and out, so the join needs no copies): plain
                 // moves under the branch's lane mask cost half of what selects on the mask do (tools/ubench: 2.3 vs 4.2 cycles)
                 asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.x) : "v"(cam_v.x));  // camera.rs:43-50
@@ -1126,7 +1088,6 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.z));
                 asm volatile("v_mov_b32 %0, 0" : "+v"(bounce));
                 asm volatile("v_mov_b32 %0, -1" : "+v"(self));  // RT_NONE
-#endif
             } else {
                 // random_unit_vector — lambertian_diffuse.rs:39-45, metal.rs:31-37 (a first, then z); v_sin/v_cos take revolutions
                 const float z = fmaf(2.0f, ub, -1.0f);
@@ -1169,25 +1130,12 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                         dead = false;
                     }
                 }
-#if RT_STATE_MOVES
                 asm volatile("v_add_u32 %0, 1, %0" : "+v"(bounce));
                 asm volatile("v_mov_b32 %0, %1" : "+v"(self) : "v"(h.shape));  // the ray starts on the shape it hit (the hit point is in r.o already)
-#endif
             }
-            // The rest of the path state as SELECTS in straight-line code, one v_cndmask each. Written as assignments inside the
-            // two branches (or as C++ selects on the branch condition, which the compiler turns back into that) they become phi
-            // copies on both sides of the join: ~25 moves per iteration. Hence the asm.
-#if !RT_STATE_MOVES
-            const unsigned long long fm = __ballot(fresh);
-            asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r.o.x) : "v"(cam_v.x), "s"(fm));  // camera.rs:43-50 | the hit point (already in r.o)
-            asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r.o.y) : "v"(cam_v.y), "s"(fm));
-            asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r.o.z) : "v"(cam_v.z), "s"(fm));
-            asm("v_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(T.x) : "s"(fm));
-            asm("v_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(T.y) : "s"(fm));
-            asm("v_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(T.z) : "s"(fm));
-            bounce = fresh ? 0u : bounce + 1u;
-            asm("v_cndmask_b32_e64 %0, %1, -1, %2" : "=v"(self) : "v"(h.shape), "s"(fm));  // RT_NONE | the shape the ray starts on
-#endif
+            // (The path state is updated by the asm moves inside the two branches above. Written as C++ assignments there — or as
+            // C++ selects on the branch condition, which the compiler turns back into that — the updates become phi copies on both
+            // sides of the join: ~25 moves per iteration.)
             set_dir(nd);
         };
         if constexpr (!POOL) {
