@@ -147,8 +147,11 @@ def render_adaptive(flat, cam: abi.Camera, params: abi.RenderParams, state: Adap
     return st.as_dict()
 
 
-def render(flat, cam: abi.Camera, params: abi.RenderParams, precision=64, threads=0, crop=None, prior_samples=0, sum_in=None):
-    """Returns (rgba8 (h,w,4) u8, sum (h,w,3) f64, stats dict, seconds). Rows are y-up (row 0 = bottom)."""
+def render(flat, cam: abi.Camera, params: abi.RenderParams, precision=64, threads=0, crop=None, prior_samples=0, sum_in=None, accel=False):
+    """Returns (rgba8 (h,w,4) u8, sum (h,w,3) f64, stats dict, seconds). Rows are y-up (row 0 = bottom).
+    accel: answer the closest-hit / any-hit queries from a bounding-volume tree over the spheres and triangles instead of the
+    reference's linear scan — the same answers bit for bit (tests/test_oracle_accel.py), for scenes the scan cannot finish;
+    `seconds` then excludes the tree build and the test counters count the tests actually made."""
     if threads <= 0:
         threads = hw_threads()
     if crop is None:
@@ -159,8 +162,10 @@ def render(flat, cam: abi.Camera, params: abi.RenderParams, precision=64, thread
     rgba = np.zeros((h, w, 4), np.uint8)
     acc = np.zeros((h, w, 3), np.float64) if sum_in is None else np.ascontiguousarray(sum_in, dtype=np.float64).copy()
     st, secs = abi.Stats(), C.c_double(0)
-    rc = lib().oracle_render(C.byref(flat.desc), C.byref(cam), C.byref(params), cropp, prior_samples, precision, threads,
-                             rgba.ctypes.data, acc.ctypes.data, C.byref(st), C.byref(secs))
+    fn = lib().oracle_render_accel
+    fn.restype = C.c_int
+    rc = fn(C.byref(flat.desc), C.byref(cam), C.byref(params), cropp, C.c_uint64(prior_samples), C.c_int(precision), C.c_int(threads),
+            C.c_int(1 if accel else 0), C.c_void_p(rgba.ctypes.data), C.c_void_p(acc.ctypes.data), C.byref(st), C.byref(secs))
     if rc != 0:
         raise ValueError("oracle_render: bad argument")
     return rgba, acc, st.as_dict(), secs.value

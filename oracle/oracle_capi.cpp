@@ -8,6 +8,19 @@
 
 using namespace oracle;
 
+static bool valid_render_args(const rthip_scene_desc *scene, const rthip_camera *cam, const rthip_render_params *p) {
+    if (!scene || !cam || !p || p->width < 2 || p->height < 2 || p->spp == 0) return false;
+    for (uint64_t i = 0; i < scene->n_spheres; i++)
+        if (scene->spheres[i].material >= scene->n_materials) return false;
+    for (uint64_t i = 0; i < scene->n_planes; i++)
+        if (scene->planes[i].material >= scene->n_materials) return false;
+    for (uint64_t i = 0; i < scene->n_triangles; i++)
+        if (scene->triangles[i].material >= scene->n_materials) return false;
+    for (uint64_t i = 0; i < scene->n_materials; i++)
+        if (scene->materials[i].kind == RTHIP_MAT_TEXTURE && scene->materials[i].texture >= scene->n_textures) return false;
+    return true;
+}
+
 extern "C" {
 
 int oracle_hw_threads(void) { return omp_get_max_threads(); }
@@ -18,15 +31,7 @@ int oracle_hw_threads(void) { return omp_get_max_threads(); }
 int oracle_render(const rthip_scene_desc *scene, const rthip_camera *cam, const rthip_render_params *p, const uint32_t *crop,
                   uint64_t prior_samples, int precision, int threads, uint8_t *rgba8, double *sum_io, rthip_stats *stats,
                   double *seconds) {
-    if (!scene || !cam || !p || p->width < 2 || p->height < 2 || p->spp == 0) return -1;
-    for (uint64_t i = 0; i < scene->n_spheres; i++)
-        if (scene->spheres[i].material >= scene->n_materials) return -1;
-    for (uint64_t i = 0; i < scene->n_planes; i++)
-        if (scene->planes[i].material >= scene->n_materials) return -1;
-    for (uint64_t i = 0; i < scene->n_triangles; i++)
-        if (scene->triangles[i].material >= scene->n_materials) return -1;
-    for (uint64_t i = 0; i < scene->n_materials; i++)
-        if (scene->materials[i].kind == RTHIP_MAT_TEXTURE && scene->materials[i].texture >= scene->n_textures) return -1;
+    if (!valid_render_args(scene, cam, p)) return -1;
     auto t0 = std::chrono::steady_clock::now();
     if (precision == 64)
         render<double>(*scene, *cam, *p, crop, prior_samples, threads, rgba8, sum_io, stats);
@@ -36,6 +41,23 @@ int oracle_render(const rthip_scene_desc *scene, const rthip_camera *cam, const 
         return -1;
     auto t1 = std::chrono::steady_clock::now();
     if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    return 0;
+}
+
+// oracle_render with the optional accelerator (rt_oracle.hpp, build_accel): the scan's answers from a bounding-volume tree
+// over the spheres and triangles — for scenes the scan cannot finish (1e6 triangles). *seconds = the render loop alone
+// (tree build excluded, like the device's BVH build is not part of its kernel time).
+int oracle_render_accel(const rthip_scene_desc *scene, const rthip_camera *cam, const rthip_render_params *p, const uint32_t *crop,
+                        uint64_t prior_samples, int precision, int threads, int accel, uint8_t *rgba8, double *sum_io, rthip_stats *stats,
+                        double *seconds) {
+    if (!accel) return oracle_render(scene, cam, p, crop, prior_samples, precision, threads, rgba8, sum_io, stats, seconds);
+    if (!valid_render_args(scene, cam, p)) return -1;
+    if (precision == 64)
+        render<double>(*scene, *cam, *p, crop, prior_samples, threads, rgba8, sum_io, stats, nullptr, 1, seconds);
+    else if (precision == 32)
+        render<float>(*scene, *cam, *p, crop, prior_samples, threads, rgba8, sum_io, stats, nullptr, 1, seconds);
+    else
+        return -1;
     return 0;
 }
 

@@ -17,6 +17,8 @@
 // lights, max_depth) have no reference behaviour at all: this file DEFINES them.
 #pragma once
 
+#include <chrono>
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -234,6 +236,109 @@ struct Scene {
 
     uint64_t n_shapes() const { return spheres.size() + planes.size() + tris.size(); }
 
+    // ---- optional accelerator (test infrastructure of the test infrastructure) ------------------------------------------
+    // The reference scans every shape (ray.rs:47-67) and so does find_collision() below; on the million-triangle configuration
+    // that is 1e6 tests per ray. `build_accel()` puts the spheres and triangles in a median-split bounding-volume tree (boxes
+    // padded far beyond rounding) and find_collision()/occluded() then test only the shapes whose box the ray enters. The
+    // answer is the scan's answer, bit for bit: the same collide_* functions with the same FIXED window, the candidate set is a
+    // superset of the shapes that can be hit, and the scan's "later index wins on equal t" is applied explicitly. Checked
+    // against the scan itself in tests/test_oracle_accel.py.
+    struct AccelNode { Real lo[3], hi[3]; uint32_t left, right, first, count; };  // count > 0: leaf over accel_prims[first, first + count)
+    std::vector<AccelNode> accel_nodes;
+    std::vector<uint32_t> accel_prims;  // 0 .. n_spheres-1: spheres; n_spheres + i: triangle i
+    bool accel = false;
+
+    void prim_box(uint32_t prim, double lo[3], double hi[3]) const {
+        if (prim < spheres.size()) {
+            const Sphere &s = spheres[prim];
+            const double c[3] = {double(s.center.x), double(s.center.y), double(s.center.z)}, r = std::fabs(double(s.radius));
+            for (int k = 0; k < 3; k++) lo[k] = c[k] - r, hi[k] = c[k] + r;
+        } else {
+            const Tri &t = tris[prim - spheres.size()];
+            const double v[3][3] = {{double(t.v0.x), double(t.v0.y), double(t.v0.z)}, {double(t.v1.x), double(t.v1.y), double(t.v1.z)},
+                                    {double(t.v2.x), double(t.v2.y), double(t.v2.z)}};
+            for (int k = 0; k < 3; k++) lo[k] = std::min(v[0][k], std::min(v[1][k], v[2][k])), hi[k] = std::max(v[0][k], std::max(v[1][k], v[2][k]));
+        }
+        // padding: 1e-4 (float) / 1e-9 (double) of the box's size and distance from the origin, i.e. thousands of ulps
+        const double rel = sizeof(Real) == 4 ? 1e-4 : 1e-9;
+        for (int k = 0; k < 3; k++) {
+            const double pad = rel * ((hi[k] - lo[k]) + std::max(std::fabs(lo[k]), std::fabs(hi[k]))) + 1e-30;
+            lo[k] -= pad, hi[k] += pad;
+        }
+    }
+    uint32_t accel_build_range(uint32_t begin, uint32_t end, const std::vector<double> &boxes) {
+        const uint32_t me = uint32_t(accel_nodes.size());
+        accel_nodes.emplace_back();
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = begin; i < end; i++) {
+            const double *b = &boxes[6 * size_t(accel_prims[i])];
+            for (int k = 0; k < 3; k++) {
+                lo[k] = std::min(lo[k], b[k]), hi[k] = std::max(hi[k], b[3 + k]);
+                const double c = 0.5 * (b[k] + b[3 + k]);
+                clo[k] = std::min(clo[k], c), chi[k] = std::max(chi[k], c);
+            }
+        }
+        {
+            AccelNode &n = accel_nodes[me];
+            for (int k = 0; k < 3; k++) {
+                // outward rounding into Real (float boxes must still contain the double boxes)
+                n.lo[k] = Real(lo[k]), n.hi[k] = Real(hi[k]);
+                if (double(n.lo[k]) > lo[k]) n.lo[k] = std::nextafter(n.lo[k], Real(-INFINITY));
+                if (double(n.hi[k]) < hi[k]) n.hi[k] = std::nextafter(n.hi[k], Real(INFINITY));
+            }
+            n.left = n.right = 0, n.first = begin, n.count = end - begin;
+        }
+        if (end - begin <= 4) return me;
+        int axis = 0;
+        if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+        if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+        const uint32_t mid = begin + (end - begin) / 2;
+        std::nth_element(accel_prims.begin() + begin, accel_prims.begin() + mid, accel_prims.begin() + end, [&](uint32_t a, uint32_t b) {
+            const double ca = boxes[6 * size_t(a) + axis] + boxes[6 * size_t(a) + 3 + axis], cb = boxes[6 * size_t(b) + axis] + boxes[6 * size_t(b) + 3 + axis];
+            return ca < cb || (ca == cb && a < b);
+        });
+        const uint32_t l = accel_build_range(begin, mid, boxes), r = accel_build_range(mid, end, boxes);
+        accel_nodes[me].left = l, accel_nodes[me].right = r, accel_nodes[me].count = 0;
+        return me;
+    }
+    void build_accel() {
+        const size_t n = spheres.size() + tris.size();
+        accel_nodes.clear(), accel_prims.resize(n);
+        accel = n > 0;
+        if (!accel) return;
+        std::vector<double> boxes(6 * n);
+        for (size_t i = 0; i < n; i++) {
+            accel_prims[i] = uint32_t(i);
+            prim_box(uint32_t(i), &boxes[6 * i], &boxes[6 * i + 3]);
+        }
+        accel_nodes.reserve(n / 2 + 8);
+        accel_build_range(0, uint32_t(n), boxes);
+    }
+    // does the ray enter the node's box somewhere in [T_MIN, limit]? (conservative: boxes are padded, comparisons inclusive)
+    static bool accel_enters(const AccelNode &n, const Ray<Real> &ray, const Real inv[3], Real limit) {
+        const Real o[3] = {ray.origin.x, ray.origin.y, ray.origin.z}, d[3] = {ray.direction.x, ray.direction.y, ray.direction.z};
+        Real tn = Consts<Real>::T_MIN, tf = limit;
+        for (int k = 0; k < 3; k++) {
+            if (d[k] == Real(0.0)) {
+                if (o[k] < n.lo[k] || o[k] > n.hi[k]) return false;
+                continue;
+            }
+            Real t0 = (n.lo[k] - o[k]) * inv[k], t1 = (n.hi[k] - o[k]) * inv[k];
+            if (t0 > t1) std::swap(t0, t1);
+            // one more safety margin for the rounding of the two products
+            t0 -= std::fabs(t0) * Real(1e-6), t1 += std::fabs(t1) * Real(1e-6);
+            if (t0 > tn) tn = t0;
+            if (t1 < tf) tf = t1;
+        }
+        return tn <= tf;
+    }
+    // one candidate of the closest-hit query: the scan's rule (keep the old hit only if old.t < new.t: equal t, later index wins)
+    static void accel_take(bool ok, Real t, int64_t index, Real b1, Real b2, bool *have, Real *best_t, int64_t *best, Real *bb1, Real *bb2) {
+        if (!ok) return;
+        if (!*have || t < *best_t || (t == *best_t && index > *best)) *have = true, *best_t = t, *best = index, *bb1 = b1, *bb2 = b2;
+    }
+
     // Sphere::collide — sphere.rs:29-61
     static bool collide_sphere(const Sphere &s, const Ray<Real> &ray, Real t_min, Real t_max, Real *t_out) {
         Vec oc = ray.origin - s.center;
@@ -284,6 +389,44 @@ struct Scene {
         int64_t best = -1;
         int64_t index = 0;
         const Real t_min = Consts<Real>::T_MIN, t_max = Consts<Real>::T_MAX;
+        if (accel) {
+            uint64_t n_sph = 0, n_tri = 0;
+            const Real inv[3] = {Real(1.0) / ray.direction.x, Real(1.0) / ray.direction.y, Real(1.0) / ray.direction.z};
+            uint32_t stack[128];
+            int sp = 0;
+            stack[sp++] = 0;
+            while (sp > 0) {
+                const AccelNode &n = accel_nodes[stack[--sp]];
+                if (!accel_enters(n, ray, inv, have ? best_t : t_max)) continue;
+                if (n.count == 0) {
+                    stack[sp++] = n.left, stack[sp++] = n.right;
+                    continue;
+                }
+                for (uint32_t i = n.first; i < n.first + n.count; i++) {
+                    const uint32_t prim = accel_prims[i];
+                    Real t = 0, b1 = 0, b2 = 0;
+                    if (prim < spheres.size()) {
+                        n_sph++;
+                        const bool ok = collide_sphere(spheres[prim], ray, t_min, t_max, &t);  // (first: argument evaluation order is unspecified)
+                        accel_take(ok, t, int64_t(prim), 0, 0, &have, &best_t, &best, &bb1, &bb2);
+                    } else {
+                        n_tri++;
+                        const uint32_t ti = prim - uint32_t(spheres.size());
+                        const bool ok = collide_tri(tris[ti], ray, t_min, t_max, &t, &b1, &b2);
+                        accel_take(ok, t, int64_t(spheres.size() + planes.size() + ti), b1, b2, &have, &best_t, &best, &bb1, &bb2);
+                    }
+                }
+            }
+            for (size_t i = 0; i < planes.size(); i++) {
+                Real t = 0;
+                const bool ok = collide_plane(planes[i], ray, t_min, t_max, &t);
+                accel_take(ok, t, int64_t(spheres.size() + i), 0, 0, &have, &best_t, &best, &bb1, &bb2);
+            }
+            if (st) st->rays++, st->sphere_tests += n_sph, st->plane_tests += planes.size(), st->tri_tests += n_tri;
+            if (!have) return false;
+            hit->t = best_t, hit->position = ray.at(best_t), hit->shape = best, hit->b1 = bb1, hit->b2 = bb2;
+            return true;
+        }
         for (const Sphere &s : spheres) {
             Real t;
             if (collide_sphere(s, ray, t_min, t_max, &t)) {
@@ -324,6 +467,35 @@ struct Scene {
     // shape is hit with T_MIN < t < 1.
     bool occluded(const Ray<Real> &ray, rthip_stats *st) const {
         const Real t_min = Consts<Real>::T_MIN, t_max = Real(1.0);
+        if (accel) {
+            if (st) st->rays++, st->shadow_rays++, st->plane_tests += planes.size();
+            Real t, b1, b2;
+            for (const Plane &p : planes)
+                if (collide_plane(p, ray, t_min, t_max, &t)) return true;
+            const Real inv[3] = {Real(1.0) / ray.direction.x, Real(1.0) / ray.direction.y, Real(1.0) / ray.direction.z};
+            uint32_t stack[128];
+            int sp = 0;
+            stack[sp++] = 0;
+            while (sp > 0) {
+                const AccelNode &n = accel_nodes[stack[--sp]];
+                if (!accel_enters(n, ray, inv, t_max)) continue;
+                if (n.count == 0) {
+                    stack[sp++] = n.left, stack[sp++] = n.right;
+                    continue;
+                }
+                for (uint32_t i = n.first; i < n.first + n.count; i++) {
+                    const uint32_t prim = accel_prims[i];
+                    if (prim < spheres.size()) {
+                        if (st) st->sphere_tests++;
+                        if (collide_sphere(spheres[prim], ray, t_min, t_max, &t)) return true;
+                    } else {
+                        if (st) st->tri_tests++;
+                        if (collide_tri(tris[prim - spheres.size()], ray, t_min, t_max, &t, &b1, &b2)) return true;
+                    }
+                }
+            }
+            return false;
+        }
         if (st) {
             st->rays++;
             st->shadow_rays++;
@@ -579,8 +751,10 @@ struct PixelCaches {
 template <class Real>
 static void render(const rthip_scene_desc &desc, const rthip_camera &cam, const rthip_render_params &p, const uint32_t *crop,
                    uint64_t prior_samples, int threads, uint8_t *rgba8, double *sum_io, rthip_stats *stats_out,
-                   const PixelCaches *caches = nullptr) {
+                   const PixelCaches *caches = nullptr, int use_accel = 0, double *loop_seconds = nullptr) {
     Scene<Real> scene(desc);
+    if (use_accel) scene.build_accel();
+    const auto loop_t0 = std::chrono::steady_clock::now();
     const uint32_t x0 = crop ? crop[0] : 0, y0 = crop ? crop[1] : 0;
     const uint32_t cw = crop ? crop[2] : p.width, ch = crop ? crop[3] : p.height;
     const bool accumulate = (p.flags & RTHIP_F_ACCUMULATE) != 0;
@@ -663,6 +837,7 @@ static void render(const rthip_scene_desc &desc, const rthip_camera &cam, const 
             total.sky_evals += st.sky_evals; total.shadow_rays += st.shadow_rays;
         }
     }
+    if (loop_seconds) *loop_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_t0).count();
     total.rows = ch;
     total.nb_samples = nb_samples_all;
     total.pixels_traced = caches ? n_traced : uint64_t(cw) * ch;

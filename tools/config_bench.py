@@ -1,7 +1,8 @@
 """Timing of the SURVEY §8d configurations C2-C5 on one GPU (instrumented + plain runs).
 usage: python tools/config_bench.py [C2 C2d50 C2L C3 C4 C4L C5] ; env SPP_SCALE=0.25 scales the sample counts;
-CPU_CROP=64 also times the CPU oracle (f64, all host threads, brute force: it has no BVH) on a CPU_CROP^2 window in the
-middle of the frame at 1 spp (the CPU baseline of C4/C5 is a cropped window, reported in Mrays/s)."""
+CPU_CROP=64 also times the CPU oracle (f64, all host threads) on a CPU_CROP^2 window in the middle of the frame at 1 spp
+(the CPU baseline of C4/C5 is a cropped window, reported in Mrays/s) — the linear scan of ray.rs:47-67, or with
+CPU_ACCEL=1 the oracle's own bounding-volume tree (same answers, tests/test_oracle_accel.py)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
@@ -52,7 +53,8 @@ for name in names:
         from rustracer_amd import make_params
         cam = oracle.camera_lookat(-1.8, 1.0, 2.0)
         window = ((cfg["w"] - crop) // 2, (cfg["h"] - crop) // 2, crop, crop)
-        _, _, ost, secs = oracle.render(flat, cam, make_params(cfg["w"], cfg["h"], 1, cfg["depth"], 1, fl), precision=64, crop=window)
+        _, _, ost, secs = oracle.render(flat, cam, make_params(cfg["w"], cfg["h"], 1, cfg["depth"], 1, fl), precision=64, crop=window,
+                                            accel=bool(os.environ.get("CPU_ACCEL")))
         out.update(cpu_oracle_mrays_s=round(ost["rays"] / secs / 1e6, 3), cpu_threads=oracle.hw_threads(), cpu_sample=f"{crop}x{crop} window @ 1 spp, {secs:.1f} s",
                    cpu_tests_per_ray=round((ost["sphere_tests"] + ost["tri_tests"]) / max(1, ost["rays"]), 1))
     print(json.dumps(out), flush=True)
