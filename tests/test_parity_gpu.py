@@ -357,8 +357,9 @@ def test_error_behaviour():
     lib.rthip_destroy(ctx)
 
 
-def test_full_size_4k_properties(standalone_flat):
-    """BASELINE.json's full size: 3840x2160. Size-independent properties instead of an oracle render."""
+def test_full_size_4k_properties(standalone_flat, oracle_mod, default_camera):
+    """BASELINE.json's full size: 3840x2160. Size-independent properties, and every pixel of the frame against the f64 oracle:
+    at 2 spp, and at the bench's own workload (config C2: 256 spp, depth 5, seed 1 — 4.07e9 rays, ~10 s of the host's cores)."""
     import zlib
     w, h, spp, depth = 3840, 2160, 2, 5
     rt = Raytracer.new(w, h, seed=71)
@@ -394,6 +395,17 @@ def test_full_size_4k_properties(standalone_flat):
     mean = np.clip(whole.accum / np.float32(spp), 0.0, 1.0)
     want = (np.sqrt(mean.astype(np.float32)) * np.float32(255.0)).astype(np.uint8)
     assert np.abs(want.astype(int) - whole.rgba8[..., :3].astype(int)).max() <= 1
+    ref, _, st, _ = oracle_mod.render(standalone_flat, default_camera, make_params(w, h, spp, depth, 71), precision=64)
+    hist, ok = assert_parity(whole.rgba8, ref, "C2 whole 4K frame, 2 spp, vs oracle f64")
+    assert abs(s["rays"] - st["rays"]) <= 2e-3 * st["rays"]
+    bench = Raytracer.new(w, h, seed=1)
+    frame = bench.render(standalone_flat, 256, max_depth=5, want_accum=False)
+    ref256, _, st256, secs = oracle_mod.render(standalone_flat, default_camera, make_params(w, h, 256, 5, 1), precision=64)
+    hist256, ok256 = assert_parity(frame.rgba8, ref256, "C2 whole 4K frame, 256 spp (the bench workload), vs oracle f64")
+    assert abs(frame.stats["rays"] - st256["rays"]) <= 1e-3 * st256["rays"]
+    print(f"\nC2 4K vs oracle f64: 2 spp {ok * 100:.4f} % within 1/255 (max |delta| {int(np.nonzero(hist)[0].max())}); "
+          f"256 spp {ok256 * 100:.4f} % (max |delta| {int(np.nonzero(hist256)[0].max())}; oracle {secs:.1f} s, rays device {frame.stats['rays']} oracle {st256['rays']})")
+    bench.close()
     rt.close()
 
 
