@@ -409,6 +409,26 @@ def test_full_size_4k_properties(standalone_flat, oracle_mod, default_camera):
     rt.close()
 
 
+@pytest.mark.parametrize("name", ["C3", "C2+light"])
+def test_full_size_4k_other_configs_vs_oracle(oracle_mod, default_camera, name):
+    """The other 4K configurations of SURVEY §8d at their full size, every pixel against the f64 oracle: C3 (textured spheres +
+    textured quad + ground, 64 spp, depth 50) and BASELINE's literal config 2 (the standalone scene with a point light:
+    reflections at depth 5 + shadow rays; 32 spp here)."""
+    w, h = 3840, 2160
+    if name == "C3":
+        flat, spp, depth, flags = flatten(presets.textured_scene()), 64, 50, 0
+    else:
+        flat, spp, depth, flags = flatten(presets.standalone_scene(), presets.standalone_lights()), 32, 5, abi.F_POINT_LIGHTS
+    rt = Raytracer.new(w, h, seed=1)
+    frame = rt.render(flat, spp, max_depth=depth, flags=flags, want_accum=False)
+    ref, _, st, secs = oracle_mod.render(flat, default_camera, make_params(w, h, spp, depth, 1, flags), precision=64)
+    hist, ok = assert_parity(frame.rgba8, ref, f"{name} whole 4K frame vs oracle f64")
+    assert abs(frame.stats["rays"] - st["rays"]) <= 1e-3 * st["rays"]
+    print(f"\n{name} 4K {spp} spp vs oracle f64 ({secs:.1f} s): {ok * 100:.4f} % within 1/255, max |delta| {int(np.nonzero(hist)[0].max())}; "
+          f"rays device {frame.stats['rays']} oracle {st['rays']}")
+    rt.close()
+
+
 def test_full_size_8k_bvh_properties(oracle_mod, default_camera):
     """C5 at its full size: 7680x4320, 10 001 spheres + an 81 920-triangle mesh through the BVH, work pool and
     leaf-ordered records. Size-independent properties: counter identities, 8-way band split == whole frame (checksum of
