@@ -241,10 +241,11 @@ def main():
         }
         if args.rehearse:
             out["rehearsal"] = "all ranks on cuda:0, gloo collectives: not a measurement"
+        cpu_frame = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(flat)
+            out["cpu_baseline"], cpu_frame = cpu_baseline(flat)
         if world == 1 and not args.no_parity:
-            out["parity"] = parity_check(rt, flat)
+            out["parity"] = parity_check(rt, flat, cpu_frame)
         if world == 1 and not args.no_configs:
             rt.close()
             out["configs"] = config_lines(device, with_cpu=not args.no_cpu_baseline)
@@ -272,7 +273,7 @@ def cpu_baseline(flat):
     p1 = make_params(WIDTH, HEIGHT, spp1, MAX_DEPTH, 1)
     _, _, st1, s1 = oracle.render(flat, cam, p1, precision=64, threads=1)
     pn = make_params(WIDTH, HEIGHT, sppn, MAX_DEPTH, 1)
-    _, _, stn, sn = oracle.render(flat, cam, pn, precision=64, threads=threads)
+    ref, _, stn, sn = oracle.render(flat, cam, pn, precision=64, threads=threads)
     return {
         "value": round(stn["rays"] / sn / 1e6, 2),
         "unit": "Mrays/s",
@@ -282,19 +283,24 @@ def cpu_baseline(flat):
         "sample": f"full {WIDTH}x{HEIGHT} frame, max_depth {MAX_DEPTH}, f64 oracle: {sppn} spp on {threads} threads ({sn:.1f} s); "
                   f"{spp1} spp on 1 thread ({s1:.1f} s) — the reference itself renders on one thread",
         "value_1thread": round(st1["rays"] / s1 / 1e6, 2),
-    }
+    }, (ref, sppn)
 
 
-def parity_check(rt, flat):
-    """small GPU-vs-oracle (f64) parity sample with the mismatch histogram (the full matrix is in tests/)"""
+def parity_check(rt, flat, cpu_frame=None):
+    """GPU vs oracle (f64) with the mismatch histogram: on the frame the CPU baseline has just rendered — the bench's own
+    3840x2160 frame at the baseline's sample count, seed 1 — or, without a baseline, on a small sample (the full matrix is in tests/)"""
     import oracle
     from parity import mismatch_histogram
     from rustracer_amd import Raytracer, make_params
-    w, h, spp = 480, 270, 8
+    if cpu_frame is not None:
+        ref, spp = cpu_frame
+        w, h = WIDTH, HEIGHT
+    else:
+        w, h, spp = 480, 270, 8
+        cam = oracle.camera_lookat(-1.8, 1.0, 2.0)
+        ref, _, _, _ = oracle.render(flat, cam, make_params(w, h, spp, MAX_DEPTH, 1), precision=64)
     small = Raytracer.new(w, h, seed=1, device=0)
     res = small.render(flat, spp, max_depth=MAX_DEPTH, want_accum=False)
-    cam = oracle.camera_lookat(-1.8, 1.0, 2.0)
-    ref, _, _, _ = oracle.render(flat, cam, make_params(w, h, spp, MAX_DEPTH, 1), precision=64)
     hist, ok = mismatch_histogram(res.rgba8, ref)
     small.close()
     return {"vs": "oracle f64", "size": f"{w}x{h}@{spp}spp", "tolerance": "|delta|<=1/255", "fraction_within": round(ok, 6),
