@@ -227,7 +227,7 @@ def main():
             },
             "roofline": {
                 "bound": "valu_fp32",
-                "kernel": "render_kernel<STATS=false, MODE_LDS, LIGHTS=false>",
+                "kernel": "render_kernel<STATS=false, MODE_LDS, LIGHTS=false, SPH_SCENE=true>",
                 "achieved": round(achieved, 3),
                 "peak": FP32_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s",

@@ -1,6 +1,6 @@
 // rt_kernels.hip — gfx950 (CDNA4, wave64) kernels of the rustracer render path.
 //
-// render_kernel<STATS, MODE, LIGHTS>: a 256-thread workgroup = a 32x8 pixel tile, a wave = an 8x8 tile (coherent primary
+// render_kernel<STATS, MODE, LIGHTS, SPH_SCENE>: a 256-thread workgroup = a 32x8 pixel tile, a wave = an 8x8 tile (coherent primary
 // rays => coherent branches). The recursion of Ray::_project_ray (raytracer_core/src/shapes/ray.rs:69-87) is an iterative
 // bounce loop with the path state (ray, throughput, bounce count, RNG counter) in VGPRs, and the `samples` loop of
 // generate_pixel (lib.rs:281-288) is folded into the same loop by path regeneration.
@@ -373,6 +373,27 @@ __device__ __forceinline__ HitRec closest_hit_unbounded(const KernelParams &P, c
     return h;
 }
 
+// The triangles of a linear-scan scene against the closest hit so far, in index order (ray.rs:47-67 continues over them):
+// hit_tri, with a wave-level early-out after the first barycentric (same arithmetic: the skipped half would reject every lane anyway)
+__device__ __forceinline__ void tris_closest(const KernelParams &P, const Ray &r, HitRec &h) {
+    for (uint32_t i = 0; i < P.n_tris; i++) {
+        const rt_f4 v0 = P.tri_geom[3 * i], e1_ = P.tri_geom[3 * i + 1], e2_ = P.tri_geom[3 * i + 2];
+        const f3 e1 = mk3(e1_.x, e1_.y, e1_.z), e2 = mk3(e2_.x, e2_.y, e2_.z);
+        const f3 pvec = cross(r.d, e2);
+        const float det = dot(e1, pvec);
+        const float inv = fast_rcp(det);
+        const f3 tvec = mk3(r.o.x - v0.x, r.o.y - v0.y, r.o.z - v0.z);
+        const float b1 = dot(tvec, pvec) * inv;
+        const bool first = det != 0.0f && b1 >= 0.0f && b1 <= 1.0f;
+        if (__ballot(first) == 0ull) continue;
+        const f3 qvec = cross(tvec, e1);
+        const float b2 = dot(r.d, qvec) * inv;
+        const float t = dot(e2, qvec) * inv;
+        const bool ok = first && b2 >= 0.0f && (b1 + b2) <= 1.0f && t < r.tmax && t > r.tmin;
+        RT_TAKE(ok, t, P.n_spheres + P.n_planes + i, (h.b1 = b1, h.b2 = b2))
+    }
+}
+
 // SPH: the caller knows that the scene holds spheres only (no plane, no triangle): their (empty) loops are left out
 template <bool STATS, int MODE, bool SPH = false>
 __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &r, uint32_t self, uint32_t *cnt, uint32_t *s_stack,
@@ -424,31 +445,17 @@ __device__ __forceinline__ HitRec closest_hit(const KernelParams &P, const Ray &
             RT_TAKE(ok, t, i, (void)0)
         }
     }
-    if (SPH) return h;
+    if (SPH) {  // (a linear-scan mode: MODE_LDS)
+        if (STATS) cnt[RT_STAT_SPHERE] += P.n_spheres;
+        return h;
+    }
     for (uint32_t i = 0; i < P.n_planes; i++) {
         float t;
         bool ok = hit_plane(P.pln_geom[4 * i], r, t);
         RT_TAKE(ok, t, P.n_spheres + i, (void)0)
     }
     if (MODE != MODE_BVH) {
-        for (uint32_t i = 0; i < P.n_tris; i++) {
-            // hit_tri, with a wave-level early-out after the first barycentric (same arithmetic: the skipped half would
-            // reject every lane anyway)
-            const rt_f4 v0 = P.tri_geom[3 * i], e1_ = P.tri_geom[3 * i + 1], e2_ = P.tri_geom[3 * i + 2];
-            const f3 e1 = mk3(e1_.x, e1_.y, e1_.z), e2 = mk3(e2_.x, e2_.y, e2_.z);
-            const f3 pvec = cross(r.d, e2);
-            const float det = dot(e1, pvec);
-            const float inv = fast_rcp(det);
-            const f3 tvec = mk3(r.o.x - v0.x, r.o.y - v0.y, r.o.z - v0.z);
-            const float b1 = dot(tvec, pvec) * inv;
-            const bool first = det != 0.0f && b1 >= 0.0f && b1 <= 1.0f;
-            if (__ballot(first) == 0ull) continue;
-            const f3 qvec = cross(tvec, e1);
-            const float b2 = dot(r.d, qvec) * inv;
-            const float t = dot(e2, qvec) * inv;
-            const bool ok = first && b2 >= 0.0f && (b1 + b2) <= 1.0f && t < r.tmax && t > r.tmin;
-            RT_TAKE(ok, t, P.n_spheres + P.n_planes + i, (h.b1 = b1, h.b2 = b2))
-        }
+        tris_closest(P, r, h);
         if (STATS) {
             cnt[RT_STAT_SPHERE] += P.n_spheres;
             cnt[RT_STAT_TRI] += P.n_tris;
@@ -654,7 +661,8 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 #ifndef RT_PRIMARY_INLINE
 #define RT_PRIMARY_INLINE 1
 #endif
-#define RT_PRIMARY_SPHERES 64u /* the primary-inline loop keeps one reachability bit per sphere */
+#define RT_PRIMARY_SPHERES 64u
+#define RT_PRIMARY_TRIS 4u /* ... and takes scenes with at most this many triangles beside the spheres (it tests them all per primary ray) */ /* the primary-inline loop keeps one reachability bit per sphere */
 #ifndef RT_SCAN_LIGHT_WAVES
 #define RT_SCAN_LIGHT_WAVES 5
 #endif
@@ -667,7 +675,8 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 #ifndef RT_BVH_WAVES
 #define RT_BVH_WAVES 7
 #endif
-template <bool STATS, int MODE, bool LIGHTS>
+// SPH_SCENE (MODE_LDS only): the scene holds spheres only — no plane, no triangle — so their code is left out of every loop.
+template <bool STATS, int MODE, bool LIGHTS, bool SPH_SCENE>
 __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_BVH_LIGHT_WAVES : RT_SCAN_LIGHT_WAVES) : (MODE == MODE_BVH ? RT_BVH_WAVES : RT_SCAN_WAVES))) void render_kernel(const KernelParams P) {
     constexpr bool POOL = MODE == MODE_BVH;
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -1049,8 +1058,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
         // (fresh) the primary ray of a new sample. Both need one RNG pair and one normalisation; sharing
         // them halves that cost in a wave where some lanes continue and the others start a new path.
         uint32_t key_own = rt_counter(__float_as_uint(pp_own.w), P.sample0 + s_first, 0);  // !POOL: slot 0 of this pixel's next sample
-        constexpr std::integral_constant<bool, true> sph_only{};
-        constexpr std::integral_constant<bool, false> any_shape{};
+        constexpr std::integral_constant<bool, SPH_SCENE> scene_sph{};
         auto next_ray = [&](bool fresh, uint32_t pixel, uint32_t sample) {
             rt_f4 pp = pp_own;
             uint32_t k = key + RT_RNG_GOLDEN;  // RNG slot 1 + bounce
@@ -1150,7 +1158,9 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             unsigned long long pmask = ~0ull;
             bool primary_inline = false;
             // (point lights change neither: a primary ray that reaches no shape gathers no light, and the cone test is about primary rays)
-            if (!STATS && MODE == MODE_LDS && P.n_planes == 0 && P.n_tris == 0 && P.max_depth != 0) {
+            // A few triangles do not stand in the way of the primary-inline loop (it tests them all on every primary ray, after the
+            // reachable spheres); the sky-only loop needs a scene of spheres.
+            if (!STATS && MODE == MODE_LDS && P.max_depth != 0 && (SPH_SCENE || (P.n_planes == 0 && P.n_tris <= RT_PRIMARY_TRIS))) {
                 const f3 hw = mk3(P.hwx, P.hwy, P.hwz), vh = mk3(P.vhx, P.vhy, P.vhz);
                 const f3 e00 = mk3(pp_own.x, pp_own.y, pp_own.z), e10 = e00 + hw, e01 = e00 + vh, e11 = e10 + vh;
                 const f3 ec = e00 + (hw + vh) * 0.5f;
@@ -1174,7 +1184,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                     can_hit |= ch;
                     if (RT_PRIMARY_INLINE && i < 64u && __ballot(active && ch) != 0ull) pm |= 1ull << i;
                 }
-                tile_empty = __ballot(active && can_hit) == 0ull;
+                tile_empty = SPH_SCENE && __ballot(active && can_hit) == 0ull;
                 pmask = pm;
                 // worth it where paths are short: the wave's primary rays see few of the spheres (the ground, mostly)
                 primary_inline = RT_PRIMARY_INLINE && !tile_empty && P.n_spheres <= 64u && 2u * uint32_t(__popcll(pm)) <= P.n_spheres;
@@ -1260,15 +1270,20 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                                 h.shape = take ? i : h.shape;
                             }
                             h.t = -nbest;
+                            if (!SPH_SCENE) {  // ... then the triangles, as closest_hit() goes on over them (the ray starts at the camera)
+                                Ray pr = r;
+                                pr.o = cam_v;
+                                tris_closest(P, pr, h);
+                            }
                             cnt[RT_STAT_RAYS]++;
-                            ended = surface(sph_only, std::integral_constant<bool, !LIGHTS>{}) != 0;
+                            ended = surface(scene_sph, std::integral_constant<bool, !LIGHTS>{}) != 0;
 #ifdef RT_CLASS_CYCLES
                             cnt[RT_STAT_HIT0 + 3] += ended ? 1u : 0u;
 #endif
                         }
                         if (!ended) {
                             next_ray(false, 0, 0);
-                            fresh = shade(sph_only) != 0;
+                            fresh = shade(scene_sph) != 0;
                         } else {
                             fresh = true;
                         }
@@ -1297,7 +1312,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                         if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex), 0u)) == 0) cnt[RT_STAT_SHADOW] += 64;
                     }
 #endif
-                    const bool fresh = shade(any_shape) != 0;
+                    const bool fresh = shade(scene_sph) != 0;
                     if (fresh) {
                         s_done++;
                         if (s_done == n_spp) break;
@@ -1363,7 +1378,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 }
                 next = min(next + uint32_t(__popcll(need)), limit);
                 if (have) {
-                    const int st = shade(any_shape);
+                    const int st = shade(scene_sph);
                     if (st == 1) {
                         cnt[RT_STAT_PATHS]++;
                         have = false;
@@ -1520,19 +1535,20 @@ __global__ void pick_kernel(const KernelParams P, float u, float v, long long *o
 }
 
 // ---- launch wrappers (called from rthip_api.cpp) -----------------------------------------
-template <bool STATS, int MODE>
+template <bool STATS, int MODE, bool SPH_SCENE>
 static void launch_variant(const KernelParams &P, bool lights, uint32_t blocks, uint32_t lds, hipStream_t stream) {
     if (lights)
-        hipLaunchKernelGGL((render_kernel<STATS, MODE, true>), dim3(blocks * P.n_slices), dim3(256), lds, stream, P);
+        hipLaunchKernelGGL((render_kernel<STATS, MODE, true, SPH_SCENE>), dim3(blocks * P.n_slices), dim3(256), lds, stream, P);
     else
-        hipLaunchKernelGGL((render_kernel<STATS, MODE, false>), dim3(blocks * P.n_slices), dim3(256), lds, stream, P);
+        hipLaunchKernelGGL((render_kernel<STATS, MODE, false, SPH_SCENE>), dim3(blocks * P.n_slices), dim3(256), lds, stream, P);
 }
 
 template <bool STATS>
 static void launch_mode(const KernelParams &P, int mode, bool lights, uint32_t blocks, uint32_t lds, hipStream_t stream) {
-    if (mode == MODE_BVH) launch_variant<STATS, MODE_BVH>(P, lights, blocks, lds, stream);
-    else if (mode == MODE_LDS) launch_variant<STATS, MODE_LDS>(P, lights, blocks, lds, stream);
-    else launch_variant<STATS, MODE_GLOBAL>(P, lights, blocks, lds, stream);
+    if (mode == MODE_BVH) launch_variant<STATS, MODE_BVH, false>(P, lights, blocks, lds, stream);
+    else if (mode == MODE_LDS && P.n_planes == 0 && P.n_tris == 0) launch_variant<STATS, MODE_LDS, true>(P, lights, blocks, lds, stream);
+    else if (mode == MODE_LDS) launch_variant<STATS, MODE_LDS, false>(P, lights, blocks, lds, stream);
+    else launch_variant<STATS, MODE_GLOBAL, false>(P, lights, blocks, lds, stream);
 }
 
 // MODE_BVH: sample rows in the per-wave radiance ring (768 B of LDS per row and wave; measured on C4: 2 rows 77 ms, 4 rows 61 ms,

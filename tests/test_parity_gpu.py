@@ -658,7 +658,8 @@ def test_primary_inline_loop_is_exact(standalone_flat, lights):
     """Waves whose primary rays can reach at most half of the spheres trace the primary ray inline, against those spheres
     only (per-sphere cone test), and the sky-only waves skip the scene altogether — with and without point lights. The
     instrumented kernel has neither loop: same bits, same ray counts. Scenes: the standalone frame, and random scenes of
-    up to 70 spheres of all four materials (more than 64 spheres: the loop must step aside) over a ground sphere."""
+    up to 70 spheres of all four materials (more than 64 spheres: the loop must step aside) over a ground sphere, every
+    third of them with 1-4 triangles (the loop takes scenes with a few triangles: C3's quad), and the C3 scene itself."""
     from rustracer_amd import Metal, Dielectric, PointLight
     fl = abi.F_POINT_LIGHTS if lights else 0
     flat = flatten(presets.standalone_scene(), presets.standalone_lights()) if lights else standalone_flat
@@ -668,6 +669,12 @@ def test_primary_inline_loop_is_exact(standalone_flat, lights):
     assert np.array_equal(a.accum, b.accum) and np.array_equal(a.rgba8, b.rgba8)
     assert a.stats["rays"] == b.stats["rays"] and a.stats["paths"] == b.stats["paths"]
     rt.close()
+    flat3 = flatten(presets.textured_scene(), presets.standalone_lights() if lights else ())  # C3: 10 spheres + a quad of two triangles
+    rt3 = Raytracer.new(960, 540, seed=17)
+    a = rt3.render(flat3, 3, max_depth=50, flags=fl)
+    b = rt3.render(flat3, 3, max_depth=50, flags=fl | abi.F_COUNT_STATS)
+    assert np.array_equal(a.accum, b.accum) and np.array_equal(a.rgba8, b.rgba8) and a.stats["rays"] == b.stats["rays"]
+    rt3.close()
     rng = np.random.default_rng(15)
     rt = Raytracer.new(640, 360, seed=16)
     tex = presets.standalone_scene()[3].material
@@ -680,6 +687,11 @@ def test_primary_inline_loop_is_exact(standalone_flat, lights):
             mat = (Lambertian.new(rng.uniform(0.1, 0.9, 3)), Metal.new(rng.uniform(0.3, 0.9, 3), float(rng.uniform(0, 0.5))),
                    Dielectric.new((1.0, 0.9, 0.9), 1.3), tex)[kind]
             scene.append(Sphere.new(c, float(rng.choice([0.05, 0.2, 0.5])), mat))
+        if trial % 3 == 2:  # a few triangles beside the spheres: the loop tests them all on every primary ray
+            from rustracer_amd import Triangle
+            for _ in range(int(rng.integers(1, 5))):
+                v = rng.uniform(-2.5, 2.5, 3) * np.array([1.0, 0.3, 1.0]) + np.array([0.0, 0.4, -2.5])
+                scene.append(Triangle.new(v, v + rng.uniform(-1.5, 1.5, 3), v + rng.uniform(-1.5, 1.5, 3), (tex, scene[1].material)[int(rng.integers(0, 2))]))
         flat = flatten(scene, [PointLight((3.0, 4.0, 2.0), (20.0, 20.0, 20.0))] if lights else ())
         a = rt.render(flat, 3, max_depth=6, flags=fl)
         b = rt.render(flat, 3, max_depth=6, flags=fl | abi.F_COUNT_STATS)

@@ -29,7 +29,7 @@ if kt:
             render_ns.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
             meta = (row.get("VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), row.get("Grid_Size"), row.get("Workgroup_Size"))
     if render_ns:
-        lines.append(f"render_kernel<false, 0, false> (the timed kernel) dispatches: {len(render_ns)}, avg {sum(render_ns)/len(render_ns)/1e6:.3f} ms; VGPR/SGPR/LDS/grid/wg = {meta}\n")
+        lines.append(f"render_kernel<false, 0, false, true> (the timed kernel) dispatches: {len(render_ns)}, avg {sum(render_ns)/len(render_ns)/1e6:.3f} ms; VGPR/SGPR/LDS/grid/wg = {meta}\n")
 counters = defaultdict(list)
 for d in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
     f = find(f"{d}/**/*counter_collection.csv")
@@ -41,7 +41,7 @@ for d in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
         if "render_kernel<false" in row["Kernel_Name"] or ("render_kernel" in row["Kernel_Name"] and "<" not in row["Kernel_Name"]):
             counters[row["Counter_Name"]].append(float(row["Counter_Value"]))
 if counters:
-    lines.append("## PMC, per dispatch of the timed kernel render_kernel<false, 0, false> (mean over its dispatches)\n")
+    lines.append("## PMC, per dispatch of the timed kernel render_kernel<false, 0, false, true> (mean over its dispatches)\n")
     lines.append("| counter | value |\n|---|---|")
     mean = {k: sum(v) / len(v) for k, v in counters.items()}
     for k in sorted(mean):
