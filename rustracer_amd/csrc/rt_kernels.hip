@@ -673,7 +673,7 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 #define RT_SCAN_WAVES 7
 #endif
 #ifndef RT_SCAN_SPH_WAVES
-#define RT_SCAN_SPH_WAVES 8 /* the sphere-only instantiation fits 64 VGPRs without spills: 8 waves per SIMD, 0.8 % faster on C2 (the one with triangles is 13 % slower at 8) */
+#define RT_SCAN_SPH_WAVES 7 /* 8 waves (64 VGPRs) measured 0.8 % faster on C2, but its 8 spilled registers add 170 MB of scratch traffic per launch to a kernel whose outputs are 133 MB */
 #endif
 #ifndef RT_BVH_WAVES
 #define RT_BVH_WAVES 7
