@@ -103,6 +103,13 @@ int gfail(rthip_group *g, int status, const std::string &msg) {
         if (s__) return gfail(g, s__, "device " + std::to_string((g)->devices[i]) + ": " + rthip_last_error((g)->ctx[i])); \
     } while (0)
 
+// the calling thread's current device, put back when the entry point returns (the group moves it from device to device)
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
 int ensure(rthip_group *g, int device, Buf &b, size_t bytes) {
     if (bytes <= b.bytes) return RTHIP_OK;
     GHIP(g, hipSetDevice(device));
@@ -131,6 +138,7 @@ rthip_ctx *rthip_group_context(rthip_group *g, int index) { return (g && index >
 
 void rthip_group_destroy(rthip_group *g) {
     if (!g) return;
+    DeviceGuard restore_device;
     for (size_t i = 0; i < g->ctx.size(); i++) {
         if (!g->ctx[i]) continue;  // creation failed at this device (it may not even exist)
         (void)hipSetDevice(g->devices[i]);
@@ -160,6 +168,7 @@ int rthip_group_create(const int *devices, int ndev, uint32_t flags, rthip_group
     if (!devices || ndev < 1 || ndev > 64) return gfail(nullptr, RTHIP_E_BADARG, "rthip_group_create: 1..64 devices");
     if (flags & ~uint32_t(RTHIP_GROUP_F_PEER_COPY | RTHIP_GROUP_F_FORCE_RCCL)) return gfail(nullptr, RTHIP_E_BADARG, "rthip_group_create: unknown flag bits");
     if ((flags & RTHIP_GROUP_F_PEER_COPY) && (flags & RTHIP_GROUP_F_FORCE_RCCL)) return gfail(nullptr, RTHIP_E_BADARG, "rthip_group_create: contradictory flags");
+    DeviceGuard restore_device;
     rthip_group *g = nullptr;
     try {
         g = new rthip_group();
@@ -228,6 +237,7 @@ int rthip_group_render(rthip_group *g, const rthip_render_params *params, uint8_
     if (params->band_first != 0 || params->band_stride > 1)
         return gfail(g, RTHIP_E_BADARG, "rthip_group_render: band_first/band_stride belong to the group (leave them 0); band_rows = rows per band, 0 = 8");
     if (params->flags & RTHIP_F_ADAPTIVE) return gfail(g, RTHIP_E_BADARG, "rthip_group_render: RTHIP_F_ADAPTIVE is not supported across devices");
+    DeviceGuard restore_device;
     try {
         const uint32_t ndev = uint32_t(g->devices.size());
         const uint32_t W = params->width, H = params->height;
@@ -285,10 +295,13 @@ int rthip_group_render(rthip_group *g, const rthip_render_params *params, uint8_
                 GNCCL(g, g_rccl.GroupStart());
                 for (uint32_t r = first; r < ndev; r++) {
                     if (rows[r] == 0) continue;
+                    GHIP(g, hipSetDevice(g->devices[r]));  // (each call with its communicator's device current)
                     GNCCL(g, g_rccl.Send((*pl.band)[r].p, size_t(rows[r]) * pl.row_bytes, ncclUint8, 0, g->comm[r], (hipStream_t)rt_ctx_stream(g->ctx[r])));
+                    GHIP(g, hipSetDevice(d0));
                     GNCCL(g, g_rccl.Recv((char *)pl.recv->p + r * slot, size_t(rows[r]) * pl.row_bytes, ncclUint8, int(r), g->comm[0], s0));
                 }
                 GNCCL(g, g_rccl.GroupEnd());
+                GHIP(g, hipSetDevice(d0));
             } else {
                 for (uint32_t r = 1; r < ndev; r++) {
                     if (rows[r] == 0) continue;
