@@ -626,8 +626,8 @@ def test_empty_tile_fast_path_is_exact(standalone_flat):
     whose silhouettes cross many tiles, including spheres behind the camera and one around it."""
     from rustracer_amd import Metal
     rt = Raytracer.new(3840, 2160, seed=4)
-    a = rt.render(standalone_flat, 3, max_depth=5)
-    b = rt.render(standalone_flat, 3, max_depth=5, flags=abi.F_COUNT_STATS)
+    a = rt.render(standalone_flat, 4, max_depth=5)   # (the fast loops need >= 4 samples per workgroup, RT_FAST_MIN_SPP)
+    b = rt.render(standalone_flat, 4, max_depth=5, flags=abi.F_COUNT_STATS)
     assert np.array_equal(a.accum, b.accum) and np.array_equal(a.rgba8, b.rgba8)
     assert a.stats["rays"] == b.stats["rays"] and a.stats["paths"] == b.stats["paths"]
     rt.close()
@@ -644,8 +644,8 @@ def test_empty_tile_fast_path_is_exact(standalone_flat):
         if trial % 6 == 5:
             scene.append(Sphere.new((-1.8, 1.0, 2.0), 0.5, Lambertian.new((0.5, 0.5, 0.5))))   # the camera sits inside this one
         flat = flatten(scene)
-        a = rt.render(flat, 2, max_depth=4)
-        b = rt.render(flat, 2, max_depth=4, flags=abi.F_COUNT_STATS)
+        a = rt.render(flat, 4, max_depth=4)
+        b = rt.render(flat, 4, max_depth=4, flags=abi.F_COUNT_STATS)
         assert np.array_equal(a.accum, b.accum), f"trial {trial}: {(a.accum != b.accum).any(axis=2).sum()} pixels differ"
         assert a.stats["rays"] == b.stats["rays"]
         n_sky_only += int(b.stats["rays"] == b.stats["paths"])
@@ -671,8 +671,8 @@ def test_primary_inline_loop_is_exact(standalone_flat, lights):
     rt.close()
     flat3 = flatten(presets.textured_scene(), presets.standalone_lights() if lights else ())  # C3: 10 spheres + a quad of two triangles
     rt3 = Raytracer.new(960, 540, seed=17)
-    a = rt3.render(flat3, 3, max_depth=50, flags=fl)
-    b = rt3.render(flat3, 3, max_depth=50, flags=fl | abi.F_COUNT_STATS)
+    a = rt3.render(flat3, 4, max_depth=50, flags=fl)
+    b = rt3.render(flat3, 4, max_depth=50, flags=fl | abi.F_COUNT_STATS)
     assert np.array_equal(a.accum, b.accum) and np.array_equal(a.rgba8, b.rgba8) and a.stats["rays"] == b.stats["rays"]
     rt3.close()
     rng = np.random.default_rng(15)
@@ -693,8 +693,8 @@ def test_primary_inline_loop_is_exact(standalone_flat, lights):
                 v = rng.uniform(-2.5, 2.5, 3) * np.array([1.0, 0.3, 1.0]) + np.array([0.0, 0.4, -2.5])
                 scene.append(Triangle.new(v, v + rng.uniform(-1.5, 1.5, 3), v + rng.uniform(-1.5, 1.5, 3), (tex, scene[1].material)[int(rng.integers(0, 2))]))
         flat = flatten(scene, [PointLight((3.0, 4.0, 2.0), (20.0, 20.0, 20.0))] if lights else ())
-        a = rt.render(flat, 3, max_depth=6, flags=fl)
-        b = rt.render(flat, 3, max_depth=6, flags=fl | abi.F_COUNT_STATS)
+        a = rt.render(flat, 4, max_depth=6, flags=fl)
+        b = rt.render(flat, 4, max_depth=6, flags=fl | abi.F_COUNT_STATS)
         assert np.array_equal(a.accum, b.accum), f"trial {trial} ({n} spheres): {(a.accum != b.accum).any(axis=2).sum()} pixels differ"
         assert a.stats["rays"] == b.stats["rays"] and a.stats["paths"] == b.stats["paths"]
     rt.close()
