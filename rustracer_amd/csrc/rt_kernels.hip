@@ -665,7 +665,7 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 #define RT_FAST_MIN_SPP 4u /* the per-wave cone tests cost about one sample: passes of fewer samples (the 1-spp progressive pass) skip them, 4K 1 spp 0.176 -> 0.160 ms */
 #endif
 #define RT_PRIMARY_SPHERES 64u
-#define RT_PRIMARY_TRIS 4u /* ... and takes scenes with at most this many triangles beside the spheres (it tests them all per primary ray) */ /* the primary-inline loop keeps one reachability bit per sphere */
+#define RT_PRIMARY_TRIS 4u /* ... and takes scenes with at most this many planes and this many triangles beside the spheres (it tests them all per primary ray) */ /* the primary-inline loop keeps one reachability bit per sphere */
 #ifndef RT_SCAN_LIGHT_WAVES
 #define RT_SCAN_LIGHT_WAVES 5
 #endif
@@ -1164,9 +1164,9 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             unsigned long long pmask = ~0ull;
             bool primary_inline = false;
             // (point lights change neither: a primary ray that reaches no shape gathers no light, and the cone test is about primary rays)
-            // A few triangles do not stand in the way of the primary-inline loop (it tests them all on every primary ray, after the
-            // reachable spheres); the sky-only loop needs a scene of spheres.
-            if (!STATS && MODE == MODE_LDS && P.max_depth != 0 && n_spp >= RT_FAST_MIN_SPP && (SPH_SCENE || (P.n_planes == 0 && P.n_tris <= RT_PRIMARY_TRIS))) {
+            // A few planes and triangles do not stand in the way of the primary-inline loop (it tests them all on every primary ray,
+            // after the reachable spheres); the sky-only loop needs a scene of spheres.
+            if (!STATS && MODE == MODE_LDS && P.max_depth != 0 && n_spp >= RT_FAST_MIN_SPP && (SPH_SCENE || (P.n_planes <= RT_PRIMARY_TRIS && P.n_tris <= RT_PRIMARY_TRIS))) {
                 const f3 hw = mk3(P.hwx, P.hwy, P.hwz), vh = mk3(P.vhx, P.vhy, P.vhz);
                 const f3 e00 = mk3(pp_own.x, pp_own.y, pp_own.z), e10 = e00 + hw, e01 = e00 + vh, e11 = e10 + vh;
                 const f3 ec = e00 + (hw + vh) * 0.5f;
@@ -1276,9 +1276,14 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                                 h.shape = take ? i : h.shape;
                             }
                             h.t = -nbest;
-                            if (!SPH_SCENE) {  // ... then the triangles, as closest_hit() goes on over them (the ray starts at the camera)
+                            if (!SPH_SCENE) {  // ... then the planes and triangles, as closest_hit() goes on over them (the ray starts at the camera)
                                 Ray pr = r;
                                 pr.o = cam_v;
+                                for (uint32_t i = 0; i < P.n_planes; i++) {
+                                    float t;
+                                    bool ok = hit_plane(P.pln_geom[4 * i], pr, t);
+                                    RT_TAKE(ok, t, P.n_spheres + i, (void)0)
+                                }
                                 tris_closest(P, pr, h);
                             }
                             cnt[RT_STAT_RAYS]++;

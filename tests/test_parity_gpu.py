@@ -675,6 +675,12 @@ def test_primary_inline_loop_is_exact(standalone_flat, lights):
     b = rt3.render(flat3, 4, max_depth=50, flags=fl | abi.F_COUNT_STATS)
     assert np.array_equal(a.accum, b.accum) and np.array_equal(a.rgba8, b.rgba8) and a.stats["rays"] == b.stats["rays"]
     rt3.close()
+    flatp = flatten(presets.plane_scene(), presets.standalone_lights() if lights else ())
+    rtp = Raytracer.new(960, 540, seed=18)
+    a = rtp.render(flatp, 4, max_depth=50, flags=fl)
+    b = rtp.render(flatp, 4, max_depth=50, flags=fl | abi.F_COUNT_STATS)
+    assert np.array_equal(a.accum, b.accum) and np.array_equal(a.rgba8, b.rgba8) and a.stats["rays"] == b.stats["rays"]
+    rtp.close()
     rng = np.random.default_rng(15)
     rt = Raytracer.new(640, 360, seed=16)
     tex = presets.standalone_scene()[3].material
@@ -687,6 +693,11 @@ def test_primary_inline_loop_is_exact(standalone_flat, lights):
             mat = (Lambertian.new(rng.uniform(0.1, 0.9, 3)), Metal.new(rng.uniform(0.3, 0.9, 3), float(rng.uniform(0, 0.5))),
                    Dielectric.new((1.0, 0.9, 0.9), 1.3), tex)[kind]
             scene.append(Sphere.new(c, float(rng.choice([0.05, 0.2, 0.5])), mat))
+        if trial % 3 == 1:  # a ground plane (and sometimes a second, tilted one) instead of / beside the ground sphere
+            from rustracer_amd import Plane
+            scene.append(Plane.new((0.0, -0.45, 0.0), (0.0, 1.0, 0.0), (tex, scene[0].material)[trial % 2]))
+            if trial % 2:
+                scene.append(Plane.new((0.0, 0.0, -8.0), (0.2, 0.1, 1.0), scene[1].material))
         if trial % 3 == 2:  # a few triangles beside the spheres: the loop tests them all on every primary ray
             from rustracer_amd import Triangle
             for _ in range(int(rng.integers(1, 5))):
