@@ -529,13 +529,19 @@ __device__ __forceinline__ f3 random_unit_vector(uint32_t h) {
 // The cast is the hardware's v_cvt_i32_f32 (saturating, NaN -> 0: exactly Rust's `as i32`); the remainder uses the texture's
 // precomputed magic = floor(2^32 / bound) (DevTexInfo): q = mulhi(|ic|, magic) is the quotient or one below it, so one
 // correction makes it exact for every |ic| <= 2^31 — 12 instructions instead of the 40 of a generic signed 32-bit `%`.
-__device__ __forceinline__ uint32_t texture_wrap(float val, float scale, uint32_t bound, uint32_t magic) {
+__device__ __forceinline__ int32_t texture_cast(float val, float scale, uint32_t bound) {
     const float fc = val * scale * float(bound);
     int32_t ic;
     asm("v_cvt_i32_f32 %0, %1" : "=v"(ic) : "v"(fc));
+    return ic;
+}
+__device__ __forceinline__ uint32_t texture_rem(uint32_t a, uint32_t bound, uint32_t magic) {  // a % bound, a <= 2^31
+    const uint32_t rem = a - __umulhi(a, magic) * bound;
+    return rem >= bound ? rem - bound : rem;
+}
+__device__ __forceinline__ uint32_t texture_wrap_signed(int32_t ic, uint32_t bound, uint32_t magic) {
     const uint32_t a = ic < 0 ? 0u - uint32_t(ic) : uint32_t(ic);  // |ic| (2^31 for INT_MIN)
-    uint32_t rem = a - __umulhi(a, magic) * bound;
-    rem = rem >= bound ? rem - bound : rem;
+    const uint32_t rem = texture_rem(a, bound, magic);
     // Rust: w = ic % bound keeps the sign of ic; if w < 0 { w + bound }
     return (ic < 0 && rem != 0u) ? bound - rem : rem;
 }
@@ -965,8 +971,15 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                         U = h.b1, V = h.b2;
                     }
                     const DevTexInfo ti = P.tex_info[__float_as_uint(sf.r1)];  // a texture material's r1 slot holds its texture index
-                    const uint32_t txl = texture_wrap(U, sf.param, ti.width, ti.magic_w);
-                    const uint32_t tyl = texture_wrap(V, sf.param, ti.height, ti.magic_h);
+                    const int32_t icx = texture_cast(U, sf.param, ti.width), icy = texture_cast(V, sf.param, ti.height);
+                    uint32_t txl, tyl;
+                    if (__ballot((icx | icy) < 0) == 0ull) {  // the usual case (sphere coordinates in [0, 1], positive scale): no sign to carry
+                        txl = texture_rem(uint32_t(icx), ti.width, ti.magic_w);
+                        tyl = texture_rem(uint32_t(icy), ti.height, ti.magic_h);
+                    } else {
+                        txl = texture_wrap_signed(icx, ti.width, ti.magic_w);
+                        tyl = texture_wrap_signed(icy, ti.height, ti.magic_h);
+                    }
                     const uint32_t texel = P.texels[ti.first_texel + (((tyl >> 3) * ti.tiles_per_row + (txl >> 3)) << 6) + ((tyl & 7u) << 3) + (txl & 7u)];
                     const f3 c = mk3(float(texel & 255u), float((texel >> 8) & 255u), float((texel >> 16) & 255u)) * (1.0f / 255.0f);
                     emit(PRIM ? c : T * c);
