@@ -53,7 +53,7 @@ struct DevTexInfo {
     uint32_t tiles_per_row;  // ceil(width/8)
     uint32_t first_texel;    // offset into texels (in u32)
     uint32_t magic_w, magic_h;  // floor(2^32 / width), floor(2^32 / height) (0xffffffff for 1): Texture::wrap's `%` without a division
-    uint32_t _pad0, _pad1;
+    float width_f, height_f;    // float(width), float(height): the factor of Texture::wrap's val * scale * bound
 };
 
 struct DevLight { float px, py, pz, _p0, ir, ig, ib, _p1; };

@@ -529,8 +529,8 @@ __device__ __forceinline__ f3 random_unit_vector(uint32_t h) {
 // The cast is the hardware's v_cvt_i32_f32 (saturating, NaN -> 0: exactly Rust's `as i32`); the remainder uses the texture's
 // precomputed magic = floor(2^32 / bound) (DevTexInfo): q = mulhi(|ic|, magic) is the quotient or one below it, so one
 // correction makes it exact for every |ic| <= 2^31 — 12 instructions instead of the 40 of a generic signed 32-bit `%`.
-__device__ __forceinline__ int32_t texture_cast(float val, float scale, uint32_t bound) {
-    const float fc = val * scale * float(bound);
+__device__ __forceinline__ int32_t texture_cast(float val, float scale, float bound) {  // bound: the texture's width or height as a float
+    const float fc = val * scale * bound;
     int32_t ic;
     asm("v_cvt_i32_f32 %0, %1" : "=v"(ic) : "v"(fc));
     return ic;
@@ -570,7 +570,8 @@ __device__ __forceinline__ float atan2_finite(float y, float x) {
 // followed by the multiply 1.05e-7 (2 000 001 points against double) — at 13 instructions instead of 22. |x| > 1 (a rounded
 // (p - c).y / r) gives NaN like acosf, which the texture wrap's cast turns into texel row 0 like Rust's `as i32`.
 __device__ __forceinline__ float acos_over_pi(float x) {
-    const float t = fabsf(x);
+    float t = fabsf(x);
+    asm volatile("" : "+v"(t));  // |x| in a register of its own: as a source modifier it forces the eight FMAs into the long (VOP3) encoding
     float q = fmaf(t, -0x1.a56262p-12f, 0x1.164948p-9f);
     q = fmaf(t, q, -0x1.6478a2p-8f);
     q = fmaf(t, q, 0x1.4236cap-7f);
@@ -971,7 +972,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                         U = h.b1, V = h.b2;
                     }
                     const DevTexInfo ti = P.tex_info[__float_as_uint(sf.r1)];  // a texture material's r1 slot holds its texture index
-                    const int32_t icx = texture_cast(U, sf.param, ti.width), icy = texture_cast(V, sf.param, ti.height);
+                    const int32_t icx = texture_cast(U, sf.param, ti.width_f), icy = texture_cast(V, sf.param, ti.height_f);
                     uint32_t txl, tyl;
                     if (__ballot((icx | icy) < 0) == 0ull) {  // the usual case (sphere coordinates in [0, 1], positive scale): no sign to carry
                         txl = texture_rem(uint32_t(icx), ti.width, ti.magic_w);

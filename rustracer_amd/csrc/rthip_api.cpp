@@ -404,8 +404,8 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
             ti[i].width = t.width, ti[i].height = t.height;
             ti[i].tiles_per_row = (t.width + 7) / 8;
             ti[i].magic_w = t.width == 1 ? 0xffffffffu : uint32_t((1ull << 32) / t.width);
+            ti[i].width_f = float(t.width), ti[i].height_f = float(t.height);
             ti[i].magic_h = t.height == 1 ? 0xffffffffu : uint32_t((1ull << 32) / t.height);
-            ti[i]._pad0 = ti[i]._pad1 = 0;
             if (total_texels > 0xffffffffull) return fail(ctx, RTHIP_E_BADARG, "textures exceed 2^32 texels");
             ti[i].first_texel = uint32_t(total_texels);
             total_texels += size_t(ti[i].tiles_per_row) * ((t.height + 7) / 8) * 64;
