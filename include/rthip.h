@@ -136,11 +136,14 @@ enum {
     RTHIP_F_POINT_LIGHTS = 1u << 1, /* extension: direct light + shadow rays at every scattering hit */
     RTHIP_F_COUNT_STATS = 1u << 2,  /* run the instrumented kernel and fill rthip_stats counters */
     RTHIP_F_NO_BVH = 1u << 3,       /* force the brute-force linear scan (ray.rs:47-67) even for big scenes */
-    RTHIP_F_ADAPTIVE = 1u << 4      /* progressive passes with the convergence rule of lib.rs:276-313: a pixel whose 8-bit
+    RTHIP_F_ADAPTIVE = 1u << 4,     /* progressive passes with the convergence rule of lib.rs:276-313: a pixel whose 8-bit
                                        colour was the same in 5 consecutive passes (same_color_count > 3, lib.rs:244,309)
                                        becomes GenerationStatus::Final and is skipped by every later pass (lib.rs:277-279):
                                        no rays, running sum and colour unchanged. Passes after the first must also set
                                        RTHIP_F_ACCUMULATE; they trace a compacted work-list of the pixels not yet Final. */
+    RTHIP_F_TILE_LISTS = 1u << 5    /* big scenes (BVH), experimental: primary rays test their pixel's primary-visibility list (one tree walk per
+                                       8x8 tile, rt_prepass.h) instead of walking the tree themselves. Same image bit for bit; measured SLOWER
+                                       than the plain traversal, kept for A/B runs and tests. Ignored without a tree. */
 };
 
 /* GenerationStatus (lib.rs:59-64) as reported by rthip_pixel_status */

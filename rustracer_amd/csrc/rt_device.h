@@ -23,6 +23,16 @@
 #define RT_SLICE_SPP 64u
 #endif
 #define RT_MAX_SLICES 16u
+// scenes with a tree: sample groups of (at least) RT_TREE_SLICE_SPP samples, at most RT_TREE_SLICES of them, always traced by different waves
+#ifndef RT_TREE_SLICE_SPP
+#define RT_TREE_SLICE_SPP 4u
+#endif
+#ifndef RT_TREE_SLICES
+#define RT_TREE_SLICES 4u
+#endif
+#ifndef RT_TREE_SLICE_BELOW_WAVES
+#define RT_TREE_SLICE_BELOW_WAVES 300000u /* ... launches of fewer wave tiles than this are sliced */
+#endif
 #ifndef RT_SLICE_BELOW_BLOCKS
 #define RT_SLICE_BELOW_BLOCKS 20000u
 #endif /* launches of fewer workgroups than this are sliced */
@@ -130,6 +140,7 @@ struct KernelParams {
     const DevLight *lights;
     const DevBvhNodeQ *bvh_nodes;
     const rt_f4 *bvh_recs;
+    const struct RtTilePre *tile_pre;  // MODE_BVH: per wave tile of this launch, the primary-visibility list (rt_prepass.h); null = none
     // outputs
     float *accum;        // context-owned running sum, owned_rows*width*3
     float *accum_out;    // optional caller copy (may be null)

@@ -36,6 +36,7 @@
 #include "../../include/rthip.h"
 #include "rt_device.h"
 #include "rt_rng.h"
+#include "rt_prepass.h"
 
 #define RT_NONE 0xffffffffu
 #ifndef RT_SCAN_UNROLL
@@ -159,7 +160,7 @@ __device__ __forceinline__ bool hit_tri(rt_f4 v0, rt_f4 e1_, rt_f4 e2_, const Ra
 // (plane - o)/d that moves a plane by a few ulps of its coordinate, which the builder's box padding (rt_bvh.cpp)
 // covers many times over and the outward rounding of the quantiser only widens; a zero direction component gives
 // NaN on that axis, which v_min/v_max drop (conservative).
-#define RT_STACK_AT(level) s_stack[(level) * 256 + threadIdx.x]
+#define RT_STACK_AT(level) s_stack[(level) * WG_THREADS + threadIdx.x]  /* WG_THREADS: threads of the calling workgroup (template parameter) */
 
 // Traversal state of one lane; it survives across calls of bvh_run so that a lane whose ray is
 // still inside the tree can be parked while the finished lanes of its wave shade and fetch new rays.
@@ -192,6 +193,9 @@ __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
 #ifndef RT_BVH_YIELD_LANES
 #define RT_BVH_YIELD_LANES 40
 #endif
+#ifndef RT_POOL_REFILL_LANES
+#define RT_POOL_REFILL_LANES 16u
+#endif
 // Runs the traversal of every calling lane. YIELD: returns early (s.ref != RT_BVH_DONE on the
 // unfinished lanes) once RT_BVH_YIELD_LANES lanes of the wave have finished, so that the caller can
 // give them new rays instead of idling them until the slowest ray of the wave is done (ray
@@ -211,8 +215,56 @@ __device__ __forceinline__ bool slab_from_t(float ax, float bx, float ay, float 
     return tn <= tf && tn <= limit && tf >= tmin;
 }
 
+// The primitives of one leaf against the ray: ray.rs:51-65 for shapes that are not visited in index order (smaller t, or equal t
+// and larger index). ANY as in bvh_run; returns true if an any-hit query found a hit.
+template <bool STATS, int ANY>
+__device__ __forceinline__ bool leaf_test(const KernelParams &P, uint32_t ref, const Ray &r, uint32_t self, HitRec &h, bool any, uint32_t *cnt) {
+    bool found = false;
+    const uint32_t first = (ref & ~RT_BVH_LEAF_BIT) >> 2, count = (ref & 3u) + 1u;
+    for (uint32_t k = 0; k < count; k++) {
+#ifdef RT_BVH_DEBUG_UTIL
+        if (STATS) {
+            const unsigned long long ex = __ballot(true);
+            if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex), 0u)) == 0) cnt[RT_STAT_HIT0] += 64;
+            cnt[RT_STAT_HIT0 + 1]++;
+        }
+#endif
+        const rt_f4 *rec = P.bvh_recs + 3 * size_t(first + k);
+        const rt_f4 a = rec[0], b = rec[1], c = rec[2];
+        const uint32_t id = __float_as_uint(a.w);
+        if (__float_as_uint(b.w) == 0u) {
+            float t;
+            bool ok = hit_sphere(rt_f4{a.x, a.y, a.z, b.x}, r, id == self, t);
+            if (STATS) cnt[RT_STAT_SPHERE]++;
+            if (ANY == 1) {
+                found |= ok;
+            } else if (ANY == 2) {
+                found |= ok && any;
+                ok = ok && !any;
+                RT_TAKE_ANY_ORDER(ok, t, id, (void)0)
+            } else {
+                RT_TAKE_ANY_ORDER(ok, t, id, (void)0)
+            }
+        } else {
+            float t, b1, b2;
+            bool ok = hit_tri(a, b, c, r, t, b1, b2);
+            if (STATS) cnt[RT_STAT_TRI]++;
+            if (ANY == 1) {
+                found |= ok;
+            } else if (ANY == 2) {
+                found |= ok && any;
+                ok = ok && !any;
+                RT_TAKE_ANY_ORDER(ok, t, id, (h.b1 = b1, h.b2 = b2))
+            } else {
+                RT_TAKE_ANY_ORDER(ok, t, id, (h.b1 = b1, h.b2 = b2))
+            }
+        }
+    }
+    return found;
+}
+
 // ANY: 0 = closest-hit query, 1 = any-hit query, 2 = per lane (any_lane): closest-hit and shadow rays of a wave walk the tree together
-template <bool STATS, int ANY, bool YIELD>
+template <bool STATS, int ANY, bool YIELD, int WG_THREADS = 256>
 __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uint32_t self, HitRec &h, BvhState &s, BvhDeep &deep, uint32_t *cnt, uint32_t *s_stack,
                                         bool any_lane = false, const lds_u4 *s_top = nullptr, uint32_t n_top = 0) {
     const bool any = ANY == 2 ? any_lane : (ANY == 1);
@@ -302,46 +354,7 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
           if (__popcll(__ballot(ref > RT_BVH_DONE)) >= RT_BVH_LEAF_LANES) break;
         }
         if (ref > RT_BVH_DONE) {  // leaf
-            const uint32_t first = (ref & ~RT_BVH_LEAF_BIT) >> 2, count = (ref & 3u) + 1u;
-            for (uint32_t k = 0; k < count; k++) {
-#ifdef RT_BVH_DEBUG_UTIL
-                if (STATS) {
-                    const unsigned long long ex = __ballot(true);
-                    if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex), 0u)) == 0) cnt[RT_STAT_HIT0] += 64;
-                    cnt[RT_STAT_HIT0 + 1]++;
-                }
-#endif
-                const rt_f4 *rec = P.bvh_recs + 3 * size_t(first + k);
-                const rt_f4 a = rec[0], b = rec[1], c = rec[2];
-                const uint32_t id = __float_as_uint(a.w);
-                if (__float_as_uint(b.w) == 0u) {
-                    float t;
-                    bool ok = hit_sphere(rt_f4{a.x, a.y, a.z, b.x}, r, id == self, t);
-                    if (STATS) cnt[RT_STAT_SPHERE]++;
-                    if (ANY == 1) {
-                        found |= ok;
-                    } else if (ANY == 2) {
-                        found |= ok && any;
-                        ok = ok && !any;
-                        RT_TAKE_ANY_ORDER(ok, t, id, (void)0)
-                    } else {
-                        RT_TAKE_ANY_ORDER(ok, t, id, (void)0)
-                    }
-                } else {
-                    float t, b1, b2;
-                    bool ok = hit_tri(a, b, c, r, t, b1, b2);
-                    if (STATS) cnt[RT_STAT_TRI]++;
-                    if (ANY == 1) {
-                        found |= ok;
-                    } else if (ANY == 2) {
-                        found |= ok && any;
-                        ok = ok && !any;
-                        RT_TAKE_ANY_ORDER(ok, t, id, (h.b1 = b1, h.b2 = b2))
-                    } else {
-                        RT_TAKE_ANY_ORDER(ok, t, id, (h.b1 = b1, h.b2 = b2))
-                    }
-                }
-            }
+            found |= leaf_test<STATS, ANY>(P, ref, r, self, h, any, cnt);
             if (sp > 0 && !(any && found)) {
                 ref = pop();
             } else {
@@ -689,21 +702,57 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 #define RT_BVH_WAVES 7
 #endif
 // SPH_SCENE (MODE_LDS only): the scene holds spheres only — no plane, no triangle — so their code is left out of every loop.
-template <bool STATS, int MODE, bool LIGHTS, bool SPH_SCENE>
-__global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_BVH_LIGHT_WAVES : RT_SCAN_LIGHT_WAVES) : (MODE == MODE_BVH ? RT_BVH_WAVES : (SPH_SCENE ? RT_SCAN_SPH_WAVES : RT_SCAN_WAVES)))) void render_kernel(const KernelParams P) {
+#ifndef RT_POOL_WAVE_WG
+#define RT_POOL_WAVE_WG 1 /* MODE_BVH: a workgroup is ONE wave (its 8x8 tile), not the four of a 32x8 pixel group: a wave's slot, registers and LDS are
+                             free the moment IT ends — the four tiles of a group differ a lot in cost (sky / mesh silhouette), and with 256-thread
+                             workgroups a third of the resident-wave time was waves waiting for their slowest sibling */
+#endif
+#define RT_WG_THREADS(MODE) (((MODE) == MODE_BVH && RT_POOL_WAVE_WG) ? 64 : 256)
+#ifndef RT_ROW_ROTATE
+#define RT_ROW_ROTATE 3u
+#endif
+template <bool STATS, int MODE, bool LIGHTS, bool SPH_SCENE, bool LISTS = false>
+__global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_BVH_LIGHT_WAVES : RT_SCAN_LIGHT_WAVES) : (MODE == MODE_BVH ? RT_BVH_WAVES : (SPH_SCENE ? RT_SCAN_SPH_WAVES : RT_SCAN_WAVES)))) void render_kernel(const KernelParams P) {
     constexpr bool POOL = MODE == MODE_BVH;
+    constexpr uint32_t WGT = RT_WG_THREADS(MODE);  // threads of this workgroup; a pixel group (32x8 pixels, or 256 work-list entries) is 256 / WGT workgroups
+    constexpr uint32_t WGW = WGT / 64u;           // ... its waves
+    // Position of this thread / workgroup in the launch's sequence of 256-pixel groups. Workgroups go to the 8 XCDs round-robin
+    // by their index, and a row of a 4K / 8K frame is a multiple of 8 groups: with the plain row-major order every XCD would
+    // own fixed COLUMNS of the picture (15 stripes at 4K) and the launch would end with whichever XCD got the expensive
+    // ones. So each row of tiles starts RT_ROW_ROTATE columns further to the right than the one below it (wrapping around):
+    // an XCD's tiles lie on diagonals. Which workgroup traces a tile has no effect on the image.
+    uint32_t tid, bid;
+    {
+        const uint32_t units_x = ((P.width + RT_TILE_W - 1u) / RT_TILE_W) * (256u / WGT);  // workgroups per row of tiles
+        const uint32_t per = P.n_slices * units_x;                                       // ... times the slices (the fast index)
+        uint32_t b = blockIdx.x;
+        if (RT_ROW_ROTATE != 0u && !P.worklist) {
+            const uint32_t row = b / per, rest = b - row * per;
+            const uint32_t u = rest / P.n_slices, sl = rest - u * P.n_slices;
+            const uint32_t c = (u + RT_ROW_ROTATE * row) % units_x;
+            b = row * per + c * P.n_slices + sl;
+        }
+        if (WGT == 256u) {
+            tid = threadIdx.x, bid = b;
+        } else {
+            // MODE_BVH: b = (wave tile index in row-major order) * n_slices + slice -> the tile's pixel group and its place in it
+            const uint32_t wt = b / P.n_slices, sl = b - wt * P.n_slices;
+            tid = ((wt & 3u) << 6) | threadIdx.x;
+            bid = (wt >> 2) * P.n_slices + sl;
+        }
+    }
     extern __shared__ __align__(16) unsigned char s_dyn[];
     rt_f4 *s_geom_mem = (rt_f4 *)s_dyn;
     rt_f4 *s_shade_mem = s_geom_mem + (MODE == MODE_LDS ? RT_LDS_SPHERES : 0u);  // fixed offsets: folded into the ds_read offset field
     uint32_t *s_stack = (uint32_t *)(s_shade_mem + (MODE == MODE_LDS ? RT_SHADE_RECS * P.n_spheres : 0u));
-    uint2 *s_pix_all = (uint2 *)(s_stack + (MODE == MODE_BVH ? P.bvh_levels * 256u : 0u));  // per pixel {RNG key, x | y << 16}
-    float *s_L_all = (float *)(s_pix_all + 256);
+    uint2 *s_pix_all = (uint2 *)(s_stack + (MODE == MODE_BVH ? P.bvh_levels * WGT : 0u));  // per pixel {RNG key, x | y << 16}
+    float *s_L_all = (float *)(s_pix_all + WGT);
     // MODE_BVH: the staged top of the tree sits behind the ring and its row counters (rt_launch_render sizes it)
-    lds_u4 *s_top = (lds_u4 *)((uint32_t *)(s_L_all + 4u * 3u * (P.ring_rows << 6)) + 64);
+    lds_u4 *s_top = (lds_u4 *)((uint32_t *)(s_L_all + WGW * 3u * (P.ring_rows << 6)) + 16u * WGW);
     const uint32_t n_top = (RT_BVH_TOP_NODES > 0 && MODE == MODE_BVH) ? P.bvh_top_nodes : 0u;
     if (RT_BVH_TOP_NODES > 0 && MODE == MODE_BVH && n_top) {
         const lds_u4 *src = (const lds_u4 *)P.bvh_nodes;
-        for (uint32_t i = threadIdx.x; i < 2u * n_top; i += 256) s_top[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < 2u * n_top; i += WGT) s_top[i] = src[i];
         __syncthreads();
     }
     const rt_f4 *s_geom = s_geom_mem;
@@ -723,7 +772,8 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
         }
         __syncthreads();
     }
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = tid >> 6, lane = threadIdx.x & 63u;  // wave: which of the pixel group's four 8x8 tiles
+    const uint32_t lwave = threadIdx.x >> 6;                   // ... and which wave of this workgroup (its share of the LDS)
     // Sample slicing (strong scaling): a workgroup traces samples [slice*slice_spp, ...) of its pixels, so that a workgroup
     // lives for at most slice_spp samples however large spp is — with one workgroup per tile for all 256 spp, the last
     // workgroups of a 1/8-frame launch ran for a third of the kernel on a mostly idle GPU (73 % kernel efficiency at 8 GPUs).
@@ -733,15 +783,15 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
     const bool sliced = P.n_slices > 1;
     // the slice is the FAST index of the grid: the slices of a tile are scheduled together, so that the launch ends with the
     // last (cheap, sky) tiles of the image rather than with the expensive tiles of its last slice
-    const uint32_t slice = sliced ? blockIdx.x % P.n_slices : 0u;
-    const uint32_t group = sliced ? blockIdx.x / P.n_slices : blockIdx.x;  // tile (or block of the work-list)
+    const uint32_t slice = sliced ? bid % P.n_slices : 0u;
+    const uint32_t group = sliced ? bid / P.n_slices : bid;  // tile (or block of the work-list)
     const uint32_t s_first = slice * P.slice_spp;
     const uint32_t n_spp = sliced ? min(P.slice_spp, P.spp - s_first) : P.spp;
     uint32_t x, lrow;
     bool listed = true;
     if (P.worklist) {
         // RTHIP_F_ADAPTIVE, pass >= 2: thread i traces the i-th pixel that is not yet Final (compact_kernel)
-        const uint32_t gi = group * 256u + threadIdx.x;
+        const uint32_t gi = group * 256u + tid;
         listed = gi < *P.worklist_count;
         const uint32_t oi = listed ? P.worklist[gi] : 0u;
         lrow = oi / P.width;
@@ -772,11 +822,21 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
     uint32_t dbg_shard = 255u;  // debug: counters filed per reachability mask of the wave (255 = sky-only / other loops)
 #endif
 
+#ifdef RT_TIMELINE  // debug build (tools/timeline.py): when and where each wave ran, written over the first pixels of its tile
+    const unsigned long long tl_start = wall_clock64();
+#endif
     if (amask != 0ull) {
-        uint2 *s_pix = s_pix_all + (wave << 6);
+        uint2 *s_pix = s_pix_all + (lwave << 6);
+        // MODE_BVH: this wave tile's primary-visibility list (rt_prepass.h), if the launch made them and the tile's fits
+        const RtTilePre *pre_tile = nullptr;
+        const RtTileEnt *pre_list = nullptr;
+        if (POOL && LISTS && P.tile_pre != nullptr && !P.worklist) {
+            pre_tile = P.tile_pre + (size_t(group) * 4u + wave);
+            if (uint32_t(__builtin_amdgcn_readfirstlane(int(pre_tile->ent[0].ref))) != RT_PRE_OVERFLOW) pre_list = pre_tile->ent;
+        }
         const uint32_t plane = P.ring_rows << 6;  // floats per colour plane of the wave's radiance slots
-        float *s_L = s_L_all + wave * 3u * plane;
-        uint32_t *s_rows = (uint32_t *)(s_L_all + 4u * 3u * plane) + (wave << 4);  // MODE_BVH: per ring slot, the paths that have ended
+        float *s_L = s_L_all + lwave * 3u * plane;
+        uint32_t *s_rows = (uint32_t *)(s_L_all + WGW * 3u * plane) + (lwave << 4);  // MODE_BVH: per ring slot, the paths that have ended
         rt_f4 pp_own;
         {
             // per pixel: direction through its lower-left corner d00 + H*x/(W-1) + V*y/(H-1) (camera.rs:46-48,
@@ -1051,8 +1111,8 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 }
                 if (tracing) {
                     bool blocked;
-                    if (LIGHTS) blocked = bvh_run<STATS, 2, true>(P, r, lit ? h.shape : self, h, bs, deep, cnt, s_stack, lit != 0u, s_top, n_top);
-                    else blocked = bvh_run<STATS, 0, true>(P, r, self, h, bs, deep, cnt, s_stack, false, s_top, n_top);
+                    if (LIGHTS) blocked = bvh_run<STATS, 2, true, int(WGT)>(P, r, lit ? h.shape : self, h, bs, deep, cnt, s_stack, lit != 0u, s_top, n_top);
+                    else blocked = bvh_run<STATS, 0, true, int(WGT)>(P, r, self, h, bs, deep, cnt, s_stack, false, s_top, n_top);
                     if (bs.ref != RT_BVH_DONE) return 2;  // parked: the finished lanes of the wave shade and fetch new work
                     tracing = false;
                     if (LIGHTS && lit) {  // the shadow ray of light lit - 1 has left the tree
@@ -1371,6 +1431,42 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             uint32_t next = 0;      // first item not yet handed out (wave-uniform)
             uint32_t oldest = 0;    // first sample row not yet retired (wave-uniform)
             bool have = false;      // this lane is tracing a path
+#ifdef RT_PRE_DEBUG
+            const unsigned long long t_pool0 = wall_clock64();
+#endif
+            // Primary ray through the tile's primary-visibility list (rt_prepass.h), for the lanes that have just taken an item:
+            // they test the leaves of their pixel's mask in order of distance — together, coherently, with no node visit and
+            // no stack — and shade the hit, so that what joins the traversing lanes below is their BOUNCE ray. Once the next
+            // leaf's box lies beyond the best hit the rest of the (sorted) list cannot matter; a hit that is not nearer than
+            // the pixel's cut distance (leaves that did not fit the tile's list) is not final: that ray goes on as a normal
+            // traversal, keeping its best hit (3). Otherwise returns what shade() returns.
+            auto primary_listed = [&]() -> int {
+                h = closest_hit_unbounded<STATS>(P, r, cnt);
+                cnt[RT_STAT_RAYS]++;
+                const uint32_t pix = item & 63u;
+                const unsigned long long m0 = pre_tile->mask[pix];
+                const float cut = pre_tile->cut[pix];
+                uint32_t mlo = uint32_t(m0), mhi = uint32_t(m0 >> 32);
+                for (;;) {
+                    uint32_t leaf = RT_BVH_DONE;
+                    if ((mlo | mhi) != 0u) {
+                        const uint32_t bit = mlo ? uint32_t(__builtin_ctz(mlo)) : 32u + uint32_t(__builtin_ctz(mhi));
+                        if (mlo) mlo &= mlo - 1u;
+                        else mhi &= mhi - 1u;
+                        const RtTileEnt e = pre_list[bit];
+                        if (e.near > h.t) mlo = mhi = 0u;
+                        else leaf = e.ref;
+                    }
+                    if (__ballot(leaf != RT_BVH_DONE) == 0ull) break;
+                    if (leaf != RT_BVH_DONE) (void)leaf_test<STATS, 0>(P, leaf, r, RT_NONE, h, false, cnt);
+                }
+                if (!(h.t < cut)) {
+                    bvh_begin(r, bs);
+                    tracing = true;
+                    return 3;
+                }
+                return surface(scene_sph, std::integral_constant<bool, false>{});
+            };
             for (;;) {
                 // ---- retire the rows whose paths have all ended ----
                 while (oldest < n_spp && uint32_t(__builtin_amdgcn_readfirstlane(int(s_rows[oldest & (rows - 1u)]))) == expect) {
@@ -1393,15 +1489,41 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 // ---- idle lanes take the next items, in lane order ----
                 const uint32_t limit = min(total, (oldest + rows) << 6);
                 const unsigned long long need = __ballot(!have);
+                bool took = false;
                 if (!have) {
                     const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi(uint32_t(need >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(need), 0u));
                     if (idx < limit && ((amask >> (idx & 63u)) & 1ull)) {
                         item = (((idx >> 6) & (rows - 1u)) << 6) | (idx & 63u);
                         have = true;
+                        took = true;
                         next_ray(true, idx & 63u, P.sample0 + s_first + (idx >> 6));
                     }
                 }
                 next = min(next + uint32_t(__popcll(need)), limit);
+                if (LISTS && pre_list != nullptr && P.max_depth != 0u) {
+#ifdef RT_PRE_DEBUG
+                    const unsigned long long t_p0 = wall_clock64();
+#endif
+                    if (took) {
+                        const int st = primary_listed();
+                        if (st == 1) {
+                            cnt[RT_STAT_PATHS]++;
+                            have = false;
+                            atomicAdd(&s_rows[item >> 6], 1u);
+                        } else if (st == 0) {
+                            next_ray(false, 0, 0);
+                        }
+                    }
+#ifdef RT_PRE_DEBUG
+                    if (lane == 0u) cnt[RT_STAT_PIX_TRACED] += uint32_t(wall_clock64() - t_p0);
+#endif
+                    // keep the traversal below full: while many lanes are without a path (their primary ray reached the sky) and
+                    // items are left to hand out, hand out again first
+                    if (uint32_t(__popcll(__ballot(!have))) >= RT_POOL_REFILL_LANES && next < limit) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        continue;
+                    }
+                }
                 if (have) {
                     const int st = shade(scene_sph);
                     if (st == 1) {
@@ -1414,6 +1536,9 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
+#ifdef RT_PRE_DEBUG
+            if (lane == 0u) cnt[RT_STAT_PIX_FINAL] += uint32_t(wall_clock64() - t_pool0);
+#endif
         }
         if (active) {
             const size_t oi = size_t(lrow) * P.width + x;
@@ -1424,6 +1549,14 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
             } else {
                 finish_pixel(P, oi, acc, cnt[RT_STAT_PIX_TRACED], cnt[RT_STAT_PIX_FINAL]);
             }
+#ifdef RT_TIMELINE
+            if (P.rgba8 && lane < 6u) {
+                const unsigned long long tl_end = wall_clock64();
+                const uint32_t v[6] = {uint32_t(tl_start), uint32_t(tl_start >> 32), uint32_t(tl_end), uint32_t(tl_end >> 32),
+                                       uint32_t(__builtin_amdgcn_s_getreg(63492)), uint32_t(__builtin_amdgcn_s_getreg(63508))};
+                P.rgba8[oi] = v[lane];
+            }
+#endif
         }
     }
 
@@ -1440,7 +1573,7 @@ __global__ __launch_bounds__(256, STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_B
 #ifdef RT_CLASS_CYCLES
         if (lane == 0 && v) atomicAdd(&P.stats[dbg_shard * RT_STAT_N + i], (unsigned long long)v);
 #else
-        if (lane == 0 && v) atomicAdd(&P.stats[((blockIdx.x * 4u + wave) & (RT_STAT_SHARDS - 1)) * RT_STAT_N + i], (unsigned long long)v);
+        if (lane == 0 && v) atomicAdd(&P.stats[((bid * 4u + wave) & (RT_STAT_SHARDS - 1)) * RT_STAT_N + i], (unsigned long long)v);
 #endif
     }
 }
@@ -1543,6 +1676,142 @@ extern "C" hipError_t rt_launch_compact(const KernelParams *P, uint32_t *list, u
     return hipGetLastError();
 }
 
+// ---- primary-visibility lists (MODE_BVH; rt_prepass.h) ---------------------------------------------------------------
+// One wave per 8x8 wave tile of the render launch (same workgroup -> tile map as render_kernel, so record group*4 + wave
+// belongs to that wave of that workgroup). The wave walks the tree breadth-first with the tile's pyramid — lane i tests the
+// two children of the i-th node of the current level, survivors are appended with ballot + prefix count — collects the leaves
+// it touches (at most RT_PRE_COLLECT), ranks them by (near, reference), keeps the RT_PRE_LEAVES nearest, and every lane
+// (pixel) marks the kept leaves its own pyramid touches and the nearest dropped one. Host mirror: rt_prepass_host.cpp.
+__device__ __forceinline__ uint32_t wave_prefix(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+}
+__global__ __launch_bounds__(256) void prepass_kernel(const KernelParams P, RtTilePre *__restrict__ out) {
+    __shared__ uint32_t s_front[4][2][RT_PRE_FRONT];
+    __shared__ uint32_t s_ref[4][RT_PRE_COLLECT];
+    __shared__ float s_near[4][RT_PRE_COLLECT];
+    __shared__ uint32_t s_rank[4][RT_PRE_COLLECT];
+    __shared__ float s_box[4][RT_PRE_COLLECT][6];
+    __shared__ RtTileEnt s_ent[4][RT_PRE_LEAVES];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t group = blockIdx.x;
+    // the pixel of this lane, as in render_kernel
+    const uint32_t tiles_x = (P.width + RT_TILE_W - 1u) / RT_TILE_W;
+    const uint32_t tile_x = group % tiles_x, tile_y = group / tiles_x;
+    const uint32_t x = tile_x * RT_TILE_W + ((wave % (RT_TILE_W / 8u)) << 3) + (lane & 7u);
+    const uint32_t lrow = tile_y * RT_TILE_H + ((wave / (RT_TILE_W / 8u)) << 3) + (lane >> 3);
+    uint32_t y = lrow;
+    if (P.band_rows) {
+        const uint32_t k = lrow / P.band_rows;
+        y = (P.band_first + k * P.band_stride) * P.band_rows + (lrow - k * P.band_rows);
+    }
+    const bool active = x < P.width && lrow < P.owned_rows && y < P.height;
+    RtTilePre *rec = out + (size_t(group) * 4u + wave);
+    uint32_t *front[2] = {s_front[wave][0], s_front[wave][1]};
+    uint32_t nleaf = 0;
+    bool over = false;
+    const unsigned long long amask = __ballot(active);
+    if (amask != 0ull) {
+        // the tile's pixel rectangle (rows need not be contiguous when a band is not a multiple of 8 rows: their hull)
+        uint32_t xmin = active ? x : 0xffffffffu, xmax = active ? x : 0u, ymin = active ? y : 0xffffffffu, ymax = active ? y : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            xmin = min(xmin, uint32_t(__shfl_xor(int(xmin), off, 64))), xmax = max(xmax, uint32_t(__shfl_xor(int(xmax), off, 64)));
+            ymin = min(ymin, uint32_t(__shfl_xor(int(ymin), off, 64))), ymax = max(ymax, uint32_t(__shfl_xor(int(ymax), off, 64)));
+        }
+        RtPyramid tile;
+        rt_pre_pyramid(P, float(xmin) - RT_PRE_MARGIN, float(xmax + 1u) + RT_PRE_MARGIN, float(ymin) - RT_PRE_MARGIN, float(ymax + 1u) + RT_PRE_MARGIN, tile);
+        uint32_t nfront = 1, cur = 0;
+        if (lane == 0) front[0][0] = 0u;  // the root is an inner node
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        while (nfront != 0u && !over) {
+            uint32_t nnext = 0;
+            for (uint32_t base = 0; base < nfront && !over; base += 64u) {
+                const bool have = base + lane < nfront;
+                float lo[2][3], hi[2][3];
+                uint32_t child[2] = {RT_BVH_DONE, RT_BVH_DONE};
+                bool keep[2] = {false, false};
+                if (have) {
+                    const DevBvhNodeQ nd = P.bvh_nodes[front[cur][base + lane]];
+                    bool empty[2];
+                    rt_pre_decode(nd, lo, hi, empty);
+                    child[0] = nd.ref0, child[1] = nd.ref1;
+                    keep[0] = !empty[0] && !rt_pre_box_outside(tile, lo[0], hi[0]);
+                    keep[1] = !empty[1] && !rt_pre_box_outside(tile, lo[1], hi[1]);
+                }
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const bool inner = keep[c] && !(child[c] & RT_BVH_LEAF_BIT), leaf = keep[c] && (child[c] & RT_BVH_LEAF_BIT);
+                    const unsigned long long bi = __ballot(inner), bl = __ballot(leaf);
+                    const uint32_t pi = nnext + wave_prefix(bi), pl = nleaf + wave_prefix(bl);
+                    nnext += uint32_t(__popcll(bi)), nleaf += uint32_t(__popcll(bl));
+                    if (nnext > RT_PRE_FRONT || nleaf > RT_PRE_COLLECT) {
+                        over = true;  // (wave-uniform)
+                        break;
+                    }
+                    if (inner) front[cur ^ 1u][pi] = child[c];
+                    if (leaf) {
+                        s_ref[wave][pl] = child[c];
+                        s_near[wave][pl] = rt_pre_box_near(tile.o, lo[c], hi[c]);
+#pragma unroll
+                        for (int k = 0; k < 3; k++) s_box[wave][pl][k] = lo[c][k], s_box[wave][pl][3 + k] = hi[c][k];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            cur ^= 1u;
+            nfront = nnext;
+        }
+    }
+    unsigned long long mask = 0ull;
+    float cut = __builtin_inff();
+    if (!over && nleaf != 0u) {
+        // rank of every collected leaf by (near, reference): the position it would have in the sorted list
+        for (uint32_t j = lane; j < nleaf; j += 64u) {
+            const float nj = s_near[wave][j];
+            const uint32_t rj = s_ref[wave][j];
+            uint32_t rank = 0;
+            for (uint32_t k = 0; k < nleaf; k++) {
+                const float nk = s_near[wave][k];
+                rank += (nk < nj || (nk == nj && s_ref[wave][k] < rj)) ? 1u : 0u;
+            }
+            s_rank[wave][j] = rank;
+            if (rank < RT_PRE_LEAVES) s_ent[wave][rank] = RtTileEnt{rj, nj};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (active) {
+            RtPyramid px;
+            rt_pre_pyramid(P, float(x) - RT_PRE_MARGIN, float(x) + 1.0f + RT_PRE_MARGIN, float(y) - RT_PRE_MARGIN, float(y) + 1.0f + RT_PRE_MARGIN, px);
+            for (uint32_t j = 0; j < nleaf; j++) {  // (wave-uniform addresses: broadcast reads)
+                float lo[3], hi[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) lo[k] = s_box[wave][j][k], hi[k] = s_box[wave][j][3 + k];
+                if (rt_pre_box_outside(px, lo, hi)) continue;
+                const uint32_t rank = s_rank[wave][j];
+                if (rank < RT_PRE_LEAVES) mask |= 1ull << rank;
+                else cut = fminf(cut, s_near[wave][j]);
+            }
+        }
+    }
+    RtTileEnt e = RtTileEnt{RT_BVH_DONE, __builtin_inff()};
+    if (!over && lane < nleaf) e = s_ent[wave][lane];
+    if (over && lane == 0u) e.ref = RT_PRE_OVERFLOW;
+    rec->ent[lane] = e;
+    rec->mask[lane] = over ? 0ull : mask;
+    rec->cut[lane] = over ? __builtin_inff() : cut;
+}
+
+extern "C" hipError_t rt_launch_prepass(const KernelParams *P, void *tile_pre, hipStream_t stream) {
+    (void)hipGetLastError();
+    const uint32_t tiles_x = (P->width + RT_TILE_W - 1u) / RT_TILE_W, tiles_y = (P->owned_rows + RT_TILE_H - 1u) / RT_TILE_H;
+    const uint32_t blocks = tiles_x * tiles_y;
+    if (blocks == 0 || P->n_bvh_nodes == 0) return hipSuccess;
+    hipLaunchKernelGGL(prepass_kernel, dim3(blocks), dim3(256), 0, stream, *P, (RtTilePre *)tile_pre);
+    return hipGetLastError();
+}
+
 // Raytracer::get_shape — lib.rs:262-267: one un-jittered primary ray, index of the closest shape.
 __global__ void pick_kernel(const KernelParams P, float u, float v, long long *out) {
     __shared__ uint32_t s_stack[RT_BVH_MAX_DEPTH * 256];
@@ -1562,10 +1831,15 @@ __global__ void pick_kernel(const KernelParams P, float u, float v, long long *o
 // ---- launch wrappers (called from rthip_api.cpp) -----------------------------------------
 template <bool STATS, int MODE, bool SPH_SCENE>
 static void launch_variant(const KernelParams &P, bool lights, uint32_t blocks, uint32_t lds, hipStream_t stream) {
-    if (lights)
-        hipLaunchKernelGGL((render_kernel<STATS, MODE, true, SPH_SCENE>), dim3(blocks * P.n_slices), dim3(256), lds, stream, P);
-    else
-        hipLaunchKernelGGL((render_kernel<STATS, MODE, false, SPH_SCENE>), dim3(blocks * P.n_slices), dim3(256), lds, stream, P);
+    constexpr uint32_t wgt = RT_WG_THREADS(MODE);  // MODE_BVH: one workgroup per wave tile, 256 / wgt workgroups per pixel group
+    const dim3 grid(blocks * P.n_slices * (256u / wgt)), block(wgt);
+    if (MODE == MODE_BVH && P.tile_pre != nullptr) {  // RTHIP_F_TILE_LISTS: the instantiation with the primary-visibility list code
+        if (lights) hipLaunchKernelGGL((render_kernel<STATS, MODE, true, SPH_SCENE, MODE == MODE_BVH>), grid, block, lds, stream, P);
+        else hipLaunchKernelGGL((render_kernel<STATS, MODE, false, SPH_SCENE, MODE == MODE_BVH>), grid, block, lds, stream, P);
+    } else {
+        if (lights) hipLaunchKernelGGL((render_kernel<STATS, MODE, true, SPH_SCENE>), grid, block, lds, stream, P);
+        else hipLaunchKernelGGL((render_kernel<STATS, MODE, false, SPH_SCENE>), grid, block, lds, stream, P);
+    }
 }
 
 template <bool STATS>
@@ -1615,7 +1889,9 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
         if (const char *e = getenv("RTHIP_BVH_TOP")) top = RT_BVH_TOP_NODES > 0 ? uint32_t(atoi(e)) : 0u;
         if (top > P.bvh_top_nodes) top = P.bvh_top_nodes;
         P.bvh_top_nodes = top;
-        lds = P.bvh_levels * 1024u + 2048u + 4u * 3u * 64u * 4u * P.ring_rows + 4u * 16u * 4u + top * 32u;
+        // per wave: stack levels x 64 lanes, 64 x {RNG key, x | y << 16}, 3 colour planes x ring rows x 64 radiance slots, 16 row counters
+        const uint32_t waves = RT_WG_THREADS(MODE_BVH) / 64u;
+        lds = waves * (P.bvh_levels * 256u + 512u + 3u * 64u * 4u * P.ring_rows + 16u * 4u) + top * 32u;
     } else {
         P.ring_rows = 1;  // lane = pixel: no radiance slots
         P.bvh_levels = 0;
@@ -1624,9 +1900,7 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
     }
     if (lds > 65536u) return hipErrorInvalidValue;
     if (P.n_slices == 0 || P.slice_spp == 0 || (P.n_slices > 1 && (uint64_t(P.n_slices) * P.slice_spp < P.spp || !P.partial))) return hipErrorInvalidValue;
-    // slice only when the launch would otherwise be too coarse to fill the GPU to its end (measured on the C2 frame:
-    // whole frame 32 400 workgroups: slicing costs 3 %; 1/8 of it: unsliced 73 %, sliced 91 % of ideal); same image either way
-    if (blocks >= RT_SLICE_BELOW_BLOCKS) P.n_slices = 1;
+    // (whether the launch is sliced — n_slices > 1 — is the caller's decision, render_pass in rthip_api.cpp; same image either way)
     if (count_stats) launch_mode<true>(P, mode, lights, blocks, lds, stream);
     else launch_mode<false>(P, mode, lights, blocks, lds, stream);
     hipError_t e = hipGetLastError();

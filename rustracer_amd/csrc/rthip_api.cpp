@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -14,7 +15,9 @@
 #include "../../include/rthip.h"
 #include "rt_bvh.h"
 #include "rt_device.h"
+#include "rt_prepass.h"
 
+extern "C" hipError_t rt_launch_prepass(const KernelParams *P, void *tile_pre, hipStream_t stream);
 extern "C" hipError_t rt_launch_render(const KernelParams *P, int count_stats, hipStream_t stream);
 extern "C" hipError_t rt_launch_compact(const KernelParams *P, uint32_t *list, uint32_t *count, hipStream_t stream);
 extern "C" hipError_t rt_launch_pick(const KernelParams *P, float u, float v, long long *d_out, hipStream_t stream);
@@ -39,7 +42,7 @@ struct rthip_ctx {
     int device = 0;
     std::string err;
     DevBuf sph_geom, sph_shade, pln_geom, tri_geom, materials, texels, tex_info, lights, bvh_nodes, bvh_recs;
-    DevBuf stats, accum, staging_rgba, staging_accum, pick_out, pix_state, worklist, partial;
+    DevBuf stats, accum, staging_rgba, staging_accum, pick_out, pix_state, worklist, partial, tile_pre;
     KernelParams base;
     bool have_scene = false, have_camera = false;
     rthip_camera camera;
@@ -58,6 +61,8 @@ struct rthip_ctx {
     unsigned long long *stats_host = nullptr;  // page-locked landing buffer of the counter shards (no staging allocation per pass)
     void *scratch = nullptr;                   // this device's copy of the static scratch array (rthip_render_device_noalloc)
     const void *acc_buffer = nullptr;          // where the running sum lives: ctx->accum.p, or the caller's d_accum (no-alloc passes)
+    const void *pre_lists = nullptr;           // the primary-visibility lists (rt_prepass.h) made for the running sum's frame, if any:
+                                               // RTHIP_F_ACCUMULATE passes of the same frame reuse them (same camera, scene, layout)
 };
 
 namespace {
@@ -148,7 +153,7 @@ int validate_params(rthip_ctx *ctx, const rthip_render_params *p) {
     // the RNG counter of a sample has 256 slots: slot 0 = pixel jitter, slot 1 + bounce = the material draws of that segment (rt_rng.h)
     if (p->max_depth > 255) return fail(ctx, RTHIP_E_BADARG, "max_depth above 255 is not supported (a deeper path would reuse the random numbers of the pixel's next sample)");
     if (p->band_rows != 0 && p->band_stride == 0) return fail(ctx, RTHIP_E_BADARG, "band_stride must be >= 1 when band_rows != 0");
-    if (p->flags & ~uint32_t(RTHIP_F_ACCUMULATE | RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_NO_BVH | RTHIP_F_ADAPTIVE))
+    if (p->flags & ~uint32_t(RTHIP_F_ACCUMULATE | RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_NO_BVH | RTHIP_F_ADAPTIVE | RTHIP_F_TILE_LISTS))
         return fail(ctx, RTHIP_E_BADARG, "unknown flag bits");
     for (int i = 0; i < 7; i++)
         if (p->reserved[i] != 0) return fail(ctx, RTHIP_E_BADARG, "reserved fields must be 0");
@@ -276,7 +281,7 @@ void rthip_destroy(rthip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->sph_geom, &ctx->sph_shade, &ctx->pln_geom, &ctx->tri_geom, &ctx->materials, &ctx->texels, &ctx->tex_info, &ctx->lights,
-                      &ctx->bvh_nodes, &ctx->bvh_recs, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out, &ctx->pix_state, &ctx->worklist, &ctx->partial})
+                      &ctx->bvh_nodes, &ctx->bvh_recs, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out, &ctx->pix_state, &ctx->worklist, &ctx->partial, &ctx->tile_pre})
         b->release();
     if (ctx->stats_host) (void)hipHostFree(ctx->stats_host);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -473,6 +478,7 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
         ctx->n_shapes = n_shapes;
         ctx->have_scene = true;
         ctx->nb_samples = 0;  // a new scene invalidates the running sum
+        ctx->pre_lists = nullptr;
         return RTHIP_OK;
     } catch (const std::bad_alloc &) {
         return fail(ctx, RTHIP_E_OOM, "host allocation failed while flattening the scene");
@@ -490,12 +496,14 @@ int rthip_set_camera(rthip_ctx *ctx, const rthip_camera *camera) {
     fill_camera(ctx->base, *camera);
     ctx->have_camera = true;
     ctx->nb_samples = 0;  // standalone/src/main.rs:103-120: a camera command invalidates the pixels
+    ctx->pre_lists = nullptr;
     return RTHIP_OK;
 }
 
 int rthip_reset_accum(rthip_ctx *ctx) {
     if (!ctx) return RTHIP_E_BADARG;
     ctx->nb_samples = 0;
+    ctx->pre_lists = nullptr;
     return RTHIP_OK;
 }
 
@@ -560,7 +568,9 @@ static int collect_stats(rthip_ctx *ctx, rthip_stats *stats) {
         stats->pixels_traced += h[sh * RT_STAT_N + RT_STAT_PIX_TRACED];
         stats->pixels_final += h[sh * RT_STAT_N + RT_STAT_PIX_FINAL];
     }
+#ifndef RT_PRE_DEBUG
     if (!ctx->pending_adaptive) stats->pixels_traced = uint64_t(ctx->pending_rows) * ctx->pending_width;
+#endif
     stats->rows = ctx->pending_rows;
     stats->nb_samples = ctx->nb_samples;
     stats->kernel_ms = ms;
@@ -623,14 +633,28 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         unsigned long long *d_stats = noalloc ? (unsigned long long *)scratch : (unsigned long long *)ctx->stats.p;
         k.stats = stats ? d_stats : nullptr;  // no reader, no counting
         if (p->flags & RTHIP_F_NO_BVH) k.n_bvh_nodes = 0;
-        // sample slicing: a function of spp alone, so that the image is the same for every band layout / GPU count
+        // Sample slicing. The GROUPING of the samples (slice_spp) is a function of spp and of the scene alone, so that the image
+        // is the same for every band layout / GPU count; whether a launch IS sliced is a scheduling decision (same image).
+        //  * scan scenes: groups of 64 samples, sliced only when the launch is too small to fill the GPU to its end;
+        //  * scenes with a tree: a wave tile's cost spans three orders of magnitude (sky: microseconds; a tile looking into the
+        //    gaps between mirror meshes at depth 50: 36 ms of a 63 ms frame, measured per wave, tools/timeline.py), and the
+        //    C4 frame ended with a fifth of its time spent on a few such waves. So the samples form up to RT_TREE_SLICES groups,
+        //    traced by different waves whenever the launch has fewer than RT_TREE_SLICE_BELOW_WAVES wave tiles (C4 at 4K:
+        //    129 600 -> sliced, 56.8 -> 52.2 ms; C5 at 8K: 518 400 -> not: its longest wave is 7 % of the frame, and every
+        //    slice costs a wave's ramp-down, 459 -> 473 ms with four).
+        const bool tree_scene = ctx->base.n_bvh_nodes > 0;  // (not k.n_bvh_nodes: RTHIP_F_NO_BVH must not change the sums)
+        uint32_t max_slices = RT_MAX_SLICES;
         k.slice_spp = RT_SLICE_SPP;
-        while (uint64_t(k.slice_spp) * RT_MAX_SLICES < p->spp) k.slice_spp *= 2;  // a power of two (the kernels mask with slice_spp - 1)
+        if (tree_scene) {
+            static const int env_slices = [] { const char *e = getenv("RTHIP_TREE_SLICES"); return e ? atoi(e) : 0; }();  // tuning knob (changes the rounding of the sums)
+            max_slices = env_slices > 0 ? uint32_t(env_slices) : RT_TREE_SLICES;
+            k.slice_spp = RT_TREE_SLICE_SPP;
+        }
+        while (uint64_t(k.slice_spp) * max_slices < p->spp) k.slice_spp *= 2;  // a power of two (the kernels mask with slice_spp - 1)
         k.n_slices = (p->spp + k.slice_spp - 1) / k.slice_spp;
-        // ... but whether the launch IS sliced only depends on its size (rt_launch_render applies the same rule)
         const uint64_t groups = (p->flags & RTHIP_F_ADAPTIVE) && accumulate ? (uint64_t(rows) * p->width + 255u) / 256u
                                                                              : uint64_t((p->width + RT_TILE_W - 1u) / RT_TILE_W) * ((rows + RT_TILE_H - 1u) / RT_TILE_H);
-        if (groups >= RT_SLICE_BELOW_BLOCKS) k.n_slices = 1;
+        if (tree_scene ? groups * 4u >= RT_TREE_SLICE_BELOW_WAVES : groups >= RT_SLICE_BELOW_BLOCKS) k.n_slices = 1;
         if (k.n_slices > 1) {
             const size_t need = size_t(k.n_slices) * rows * p->width * 3 * sizeof(float);
             if (noalloc) {
@@ -638,13 +662,39 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
                     return fail(ctx, RTHIP_E_BADARG, "rthip_render_device_noalloc: this launch is sample-sliced and needs " + std::to_string(need) +
                                                          " bytes of partial sums; the static scratch holds " +
                                                          std::to_string(size_t(RTHIP_NOALLOC_SCRATCH_BYTES - RT_NOALLOC_STATS_BYTES)) +
-                                                         " (use fewer rows per call, spp <= 64 per pass, or rthip_render_device)");
+                                                         " (use fewer rows per call, fewer samples per pass, or rthip_render_device)");
                 k.partial = (float *)(scratch + RT_NOALLOC_STATS_BYTES);  // fully written by the render kernel before resolve_kernel reads it
             } else {
                 if ((st = ensure(ctx, ctx->partial, need))) return st;
                 k.partial = (float *)ctx->partial.p;
             }
         }
+
+        // MODE_BVH: primary-visibility lists (rt_prepass.h) — the tree is walked once per 8x8 tile and the tile's primary rays
+        // test the leaves of their pixel's list. Worth it from a few samples per pixel on (the walk costs about one primary
+        // ray per pixel); the passes that continue a running sum reuse the lists of its frame (camera, scene and layout are
+        // the same by construction), a pass that starts a frame makes its own. Not for work-list passes (RTHIP_F_ADAPTIVE).
+        k.tile_pre = nullptr;
+        bool make_lists = false;
+        if (k.n_bvh_nodes > 0 && (p->flags & RTHIP_F_TILE_LISTS) && !adaptive) {
+            const size_t need = size_t(groups) * 4u * sizeof(RtTilePre);
+            if (accumulate && ctx->pre_lists) {
+                k.tile_pre = (const RtTilePre *)ctx->pre_lists;
+            } else if (p->spp >= RT_PRE_MIN_SPP || accumulate) {
+                if (noalloc) {
+                    // after the counter shards and the partial sums of a sliced launch, if the static scratch has the room
+                    size_t at = RT_NOALLOC_STATS_BYTES;
+                    if (k.n_slices > 1) at += size_t(k.n_slices) * rows * p->width * 3 * sizeof(float);
+                    at = (at + 255u) & ~size_t(255);
+                    if (at + need <= RTHIP_NOALLOC_SCRATCH_BYTES) k.tile_pre = (const RtTilePre *)(scratch + at);
+                } else {
+                    if ((st = ensure(ctx, ctx->tile_pre, need))) return st;
+                    k.tile_pre = (const RtTilePre *)ctx->tile_pre.p;
+                }
+                make_lists = k.tile_pre != nullptr;
+            }
+        }
+        if (!accumulate || !k.tile_pre) ctx->pre_lists = nullptr;
 
         // passes share the context's buffers (running sum, counters, partial sums, work-list): a pass enqueued on another
         // stream than the previous one waits for it
@@ -665,6 +715,10 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
                 HIPCHK(ctx, rt_launch_compact(&k, list, count, stream));
                 k.worklist = list, k.worklist_count = count;
             }
+        }
+        if (make_lists) {
+            HIPCHK(ctx, rt_launch_prepass(&k, (void *)k.tile_pre, stream));
+            ctx->pre_lists = noalloc ? nullptr : (const void *)k.tile_pre;  // (the static scratch is shared by every context of the GPU: not kept)
         }
         HIPCHK(ctx, rt_launch_render(&k, (p->flags & RTHIP_F_COUNT_STATS) ? 1 : 0, stream));
         if (stats) HIPCHK(ctx, hipEventRecord(ctx->ev1, stream));
@@ -699,6 +753,17 @@ int rt_ctx_render_deferred(rthip_ctx *ctx, const rthip_render_params *p, void *d
 int rt_ctx_collect_stats(rthip_ctx *ctx, rthip_stats *stats) {
     if (!ctx || !stats) return RTHIP_E_BADARG;
     return collect_stats(ctx, stats);
+}
+// internal (tests/test_prepass_gpu.py): the primary-visibility lists of the context's current frame, copied to `out`
+// (at most `bytes`); returns the size of the lists in bytes, 0 if the last pass made or used none, -1 on a HIP error
+long long rt_ctx_tile_lists(rthip_ctx *ctx, void *out, unsigned long long bytes) {
+    if (!ctx || !ctx->pre_lists) return 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+    const size_t tiles_x = (ctx->acc_width + RT_TILE_W - 1u) / RT_TILE_W, tiles_y = (ctx->acc_rows + RT_TILE_H - 1u) / RT_TILE_H;
+    const size_t have = tiles_x * tiles_y * 4u * sizeof(RtTilePre);
+    const size_t n = bytes < have ? size_t(bytes) : have;
+    if (out && n && hipMemcpy(out, ctx->pre_lists, n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long long)have;
 }
 void *rt_ctx_stream(rthip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int rt_ctx_device(rthip_ctx *ctx) { return ctx ? ctx->device : -1; }

@@ -1,0 +1,62 @@
+"""Sizes the primary-visibility lists (rt_prepass.h) on the CPU: leaves per 8x8 tile and per pixel for a config,
+from the host mirror of prepass_kernel (no GPU needed).  usage: python tools/prepass_stats.py c4|c5 [step]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from rustracer_amd import abi, flatten, presets  # noqa: E402
+from rustracer_amd.scene import Camera  # noqa: E402
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "c4"
+    if which == "c4":
+        flat, (w, h) = flatten(presets.mesh_scene()), (3840, 2160)
+    else:
+        flat, (w, h) = flatten(presets.big_scene(100, 7, 6)), (7680, 4320)
+    cam = Camera.new(-1.8, 1.0, 2.0).as_abi()
+    lib = abi.lib()
+    fn = lib.rt_prepass_host
+    fn.restype = C.c_int
+    ntx, nty = (w + 7) // 8, (h + 7) // 8
+    # a window of tile rows at a time keeps the buffers small
+    leaf_hist = np.zeros(4096, np.int64)
+    pix_sum, pix_n, pix_max, tiles_over = 0, 0, 0, {32: 0, 64: 0, 128: 0}
+    pix_hist = np.zeros(256, np.int64)
+    rows = int(sys.argv[2]) if len(sys.argv) > 2 else 8  # every `rows`-th tile row is sampled
+    t0 = time.time()
+    for ty in range(0, nty, rows):
+        lc = np.zeros(ntx, np.uint32)
+        pc = np.zeros(ntx * 64, np.uint32)
+        st = fn(C.byref(flat.desc), C.byref(cam), w, h, 0, ty, ntx, 1, None, lc.ctypes.data_as(C.c_void_p), pc.ctypes.data_as(C.c_void_p))
+        assert st == 0
+        np.add.at(leaf_hist, np.minimum(lc, 4095), 1)
+        for cap in tiles_over:
+            tiles_over[cap] += int((lc > cap).sum())
+        ok = np.repeat(lc <= 64, 64)
+        pix_sum += int(pc[ok].sum())
+        pix_n += int(ok.sum())
+        pix_max = max(pix_max, int(pc.max()))
+        np.add.at(pix_hist, np.minimum(pc[ok], 255), 1)
+    n_tiles = int(leaf_hist.sum())
+    print(f"{which}: {n_tiles} tiles sampled in {time.time() - t0:.1f} s (the tree is rebuilt per call)")
+    nz = leaf_hist[1:].sum()
+    print("tiles with no leaf:", int(leaf_hist[0]), " with leaves:", int(nz))
+    cum = np.cumsum(leaf_hist) / n_tiles
+    for q in (0.5, 0.9, 0.99):
+        print(f"  leaves per tile, quantile {q}: {int(np.searchsorted(cum, q))}")
+    print("  max leaves per tile:", int(np.nonzero(leaf_hist)[0].max()))
+    for cap, n in tiles_over.items():
+        print(f"  tiles over {cap} leaves: {n} ({100.0 * n / n_tiles:.2f} %)")
+    print(f"pixels of listed tiles: mean leaves per pixel {pix_sum / max(1, pix_n):.2f}, max {pix_max}")
+    cum = np.cumsum(pix_hist) / max(1, pix_n)
+    for q in (0.5, 0.9, 0.99):
+        print(f"  leaves per pixel, quantile {q}: {int(np.searchsorted(cum, q))}")
+
+
+if __name__ == "__main__":
+    main()
