@@ -707,7 +707,11 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
                              free the moment IT ends — the four tiles of a group differ a lot in cost (sky / mesh silhouette), and with 256-thread
                              workgroups a third of the resident-wave time was waves waiting for their slowest sibling */
 #endif
-#define RT_WG_THREADS(MODE) (((MODE) == MODE_BVH && RT_POOL_WAVE_WG) ? 64 : 256)
+#ifndef RT_SCAN_WAVE_WG
+#define RT_SCAN_WAVE_WG 0 /* the scan modes keep 256-thread workgroups: with one wave per workgroup every wave stages the scene in its own
+                             5 KB of LDS and runs its own cone tests; measured on C2: 12.17 -> 12.32 ms */
+#endif
+#define RT_WG_THREADS(MODE) (((MODE) == MODE_BVH ? RT_POOL_WAVE_WG : RT_SCAN_WAVE_WG) ? 64 : 256)
 #ifndef RT_ROW_ROTATE
 #define RT_ROW_ROTATE 3u
 #endif
@@ -723,23 +727,25 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
     // an XCD's tiles lie on diagonals. Which workgroup traces a tile has no effect on the image.
     uint32_t tid, bid;
     {
-        const uint32_t units_x = ((P.width + RT_TILE_W - 1u) / RT_TILE_W) * (256u / WGT);  // workgroups per row of tiles
-        const uint32_t per = P.n_slices * units_x;                                       // ... times the slices (the fast index)
+        constexpr uint32_t WPG = 256u / WGT;                                             // workgroups per pixel group (1, or 4 one-wave workgroups)
+        const uint32_t units_x = ((P.width + RT_TILE_W - 1u) / RT_TILE_W) * WPG;        // workgroups per row of tiles
+        const uint32_t per = P.n_slices * units_x;                                      // ... times the slices (the fast index)
         uint32_t b = blockIdx.x;
-        if (RT_ROW_ROTATE != 0u && !P.worklist) {
+        if (!P.worklist) {
             const uint32_t row = b / per, rest = b - row * per;
-            const uint32_t u = rest / P.n_slices, sl = rest - u * P.n_slices;
-            const uint32_t c = (u + RT_ROW_ROTATE * row) % units_x;
-            b = row * per + c * P.n_slices + sl;
+            uint32_t u = rest / P.n_slices;
+            const uint32_t sl = rest - u * P.n_slices;
+            // One-wave workgroups: inside every run of 32 consecutive (unsliced) workgroups the four tiles of a pixel group take
+            // indices 8 apart, i.e. the same XCD: a row of a pixel group is a whole 128-byte line of RGBA8 / 384 bytes of
+            // running sum, and lines written in part by several XCDs' L2s are read back from HBM to be merged.
+            if (WPG == 4u && P.n_slices == 1u && (units_x & 31u) == 0u) u = (u & ~31u) | ((u & 7u) << 2) | ((u >> 3) & 3u);
+            if (RT_ROW_ROTATE != 0u) u = (u + RT_ROW_ROTATE * WPG * row) % units_x;  // (whole pixel groups)
+            b = row * per + u * P.n_slices + sl;
         }
-        if (WGT == 256u) {
-            tid = threadIdx.x, bid = b;
-        } else {
-            // MODE_BVH: b = (wave tile index in row-major order) * n_slices + slice -> the tile's pixel group and its place in it
-            const uint32_t wt = b / P.n_slices, sl = b - wt * P.n_slices;
-            tid = ((wt & 3u) << 6) | threadIdx.x;
-            bid = (wt >> 2) * P.n_slices + sl;
-        }
+        // b = (index of the wave tile / pixel group in row-major order) * n_slices + slice
+        const uint32_t wt = b / P.n_slices, sl = b - wt * P.n_slices;
+        tid = WPG == 1u ? threadIdx.x : ((wt & 3u) << 6) | threadIdx.x;
+        bid = WPG == 1u ? b : (wt >> 2) * P.n_slices + sl;
     }
     extern __shared__ __align__(16) unsigned char s_dyn[];
     rt_f4 *s_geom_mem = (rt_f4 *)s_dyn;
@@ -758,11 +764,11 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
     const rt_f4 *s_geom = s_geom_mem;
     if (MODE == MODE_LDS) {
         const uint32_t n_padded = (P.n_spheres + RT_SCAN_UNROLL - 1u) & ~(RT_SCAN_UNROLL - 1u);
-        for (uint32_t i = threadIdx.x; i < n_padded; i += 256)
+        for (uint32_t i = threadIdx.x; i < n_padded; i += WGT)
             // padding: never hit. The centre is NaN, not just r*r = -inf: a padding index can equal `self` when the ray starts on a
             // plane or triangle (their shape ids follow the spheres'), which replaces c by 0 — a NaN half_b keeps the discriminant NaN
             s_geom_mem[i] = i < P.n_spheres ? P.sph_geom[i] : rt_f4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), -__builtin_inff()};
-        for (uint32_t i = threadIdx.x; i < RT_SHADE_RECS * P.n_spheres; i += 256) s_shade_mem[i] = P.sph_shade[i];
+        for (uint32_t i = threadIdx.x; i < RT_SHADE_RECS * P.n_spheres; i += WGT) s_shade_mem[i] = P.sph_shade[i];
         if (RT_PRIMARY_INLINE && threadIdx.x < RT_PRIMARY_SPHERES && threadIdx.x < P.n_spheres) {
             // what a sphere test needs of a ray's origin, for the camera (every primary ray starts there): o - c and |o - c|^2 - r^2,
             // with the very expressions of closest_hit() — the primary-inline loop reads them instead of recomputing them per ray
