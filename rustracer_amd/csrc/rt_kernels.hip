@@ -63,6 +63,10 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ f3 normalize(f3 a) { return a * fast_rsq(dot(a, a)); }
+// number of set bits of `m` below this lane's
+__device__ __forceinline__ uint32_t wave_prefix(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+}
 
 // A ray with a UNIT direction; the reference's ray has an un-normalised direction of length `len`
 // and measures t in units of it, so t_reference = t / len and the reference's fixed window
@@ -685,6 +689,14 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 #define RT_FAST_MIN_SPP 4u /* the per-wave cone tests cost about one sample: passes of fewer samples (the 1-spp progressive pass) skip them, 4K 1 spp 0.176 -> 0.160 ms */
 #endif
 #define RT_PRIMARY_SPHERES 64u
+#ifndef RT_TEX_QUEUE
+#define RT_TEX_QUEUE 0 /* 1: the variant with the deferred texture queue (librthip_texqueue.so). Bit-identical images; measured on C2: 5 % fewer
+                          VALU instructions, lane utilisation 0.66 -> 0.74, and no faster (12.27 vs 12.17 ms): 50 % more LDS instructions, 12
+                          spilled registers, +30 % wait cycles (profiles/r03_texqueue_summary.md). Off by default. */
+#endif
+// deferred texture queue, per wave: 64 entries x 9 dwords {T, a, b, c, scale, texture, meta} | 64 x u64 owner masks |
+// 2 x 3 x 64 floats: per lane, the deferred sums of the two groups in flight | 3 x 64 floats: a closed group waiting for its entries
+#define RT_QUEUE_WAVE_DWORDS (576u + 128u + 384u + 192u)
 #define RT_PRIMARY_TRIS 4u /* ... and takes scenes with at most this many planes and this many triangles beside the spheres (it tests them all per primary ray) */ /* the primary-inline loop keeps one reachability bit per sphere */
 #ifndef RT_SCAN_LIGHT_WAVES
 #define RT_SCAN_LIGHT_WAVES 5
@@ -748,8 +760,16 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
         bid = WPG == 1u ? b : (wt >> 2) * P.n_slices + sl;
     }
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    rt_f4 *s_geom_mem = (rt_f4 *)s_dyn;
-    rt_f4 *s_shade_mem = s_geom_mem + (MODE == MODE_LDS ? RT_LDS_SPHERES : 0u);  // fixed offsets: folded into the ds_read offset field
+    // DEFCLASS: the radiance of paths that end at a texture after at least one bounce is summed apart from the other samples of
+    // its group (g_k = grp_k + def_k, both in sample order) — in EVERY kernel variant, so that they all give the same bits;
+    // QUEUE: the variant that actually defers those texture evaluations to a per-wave queue (below, "deferred texture queue").
+    constexpr bool DEFCLASS = !LIGHTS;
+    constexpr bool QUEUE = RT_TEX_QUEUE != 0 && !STATS && MODE == MODE_LDS && !LIGHTS;
+    const uint32_t n_padded = (P.n_spheres + RT_SCAN_UNROLL - 1u) & ~(RT_SCAN_UNROLL - 1u);
+    // QUEUE: [per wave: the queue, RT_QUEUE_WAVE_DWORDS] [geometry, padded sphere count] [shading records] [primary table]
+    // else   [geometry, RT_LDS_SPHERES] [shading records] [primary table]  (the geometry base is a constant either way)
+    rt_f4 *s_geom_mem = (rt_f4 *)(s_dyn + (QUEUE ? WGW * RT_QUEUE_WAVE_DWORDS * 4u : 0u));
+    rt_f4 *s_shade_mem = s_geom_mem + (MODE == MODE_LDS ? (QUEUE ? n_padded : RT_LDS_SPHERES) : 0u);
     uint32_t *s_stack = (uint32_t *)(s_shade_mem + (MODE == MODE_LDS ? RT_SHADE_RECS * P.n_spheres : 0u));
     uint2 *s_pix_all = (uint2 *)(s_stack + (MODE == MODE_BVH ? P.bvh_levels * WGT : 0u));  // per pixel {RNG key, x | y << 16}
     float *s_L_all = (float *)(s_pix_all + WGT);
@@ -763,7 +783,6 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
     }
     const rt_f4 *s_geom = s_geom_mem;
     if (MODE == MODE_LDS) {
-        const uint32_t n_padded = (P.n_spheres + RT_SCAN_UNROLL - 1u) & ~(RT_SCAN_UNROLL - 1u);
         for (uint32_t i = threadIdx.x; i < n_padded; i += WGT)
             // padding: never hit. The centre is NaN, not just r*r = -inf: a padding index can equal `self` when the ray starts on a
             // plane or triangle (their shape ids follow the spheres'), which replaces c by 0 — a NaN half_b keeps the discriminant NaN
@@ -843,6 +862,8 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
         const uint32_t plane = P.ring_rows << 6;  // floats per colour plane of the wave's radiance slots
         float *s_L = s_L_all + lwave * 3u * plane;
         uint32_t *s_rows = (uint32_t *)(s_L_all + WGW * 3u * plane) + (lwave << 4);  // MODE_BVH: per ring slot, the paths that have ended
+        // ... and which of the slot's samples ended at a texture after a bounce (DEFCLASS): behind the row counters (and the staged tree top)
+        unsigned long long *s_rowdef = (unsigned long long *)((uint32_t *)(s_L_all + WGW * 3u * plane) + 16u * WGW + 8u * n_top) + (lwave << 4);
         rt_f4 pp_own;
         {
             // per pixel: direction through its lower-left corner d00 + H*x/(W-1) + V*y/(H-1) (camera.rs:46-48,
@@ -915,6 +936,51 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
                 grp = grp + L;  // lib.rs:287
             }
         };
+        // ... and the same for a path that ended at a texture after at least one bounce (DEFCLASS): those samples are summed apart
+        // from the other samples of their group, g = grp + dgrp, so that the variant of this kernel that evaluates such hits later,
+        // 64 at a time (QUEUE), adds the very same numbers in the very same order as the variants that evaluate them at once
+        f3 dgrp = mk3(0.0f, 0.0f, 0.0f);
+        auto emit_def = [&](f3 L) {
+            if constexpr (POOL) {
+                s_L[item] = L.x;
+                s_L[plane + item] = L.y;
+                s_L[2u * plane + item] = L.z;
+                atomicOr(&s_rowdef[item >> 6], 1ull << (item & 63u));  // before the row's counter moves: LDS operations of a wave stay in order
+            } else {
+                asm volatile("" : "+v"(L.x), "+v"(L.y), "+v"(L.z));
+                dgrp = dgrp + L;
+            }
+        };
+        // close a group of slice_spp samples (lane = pixel loops without a queue)
+        auto fold = [&]() {
+            if (DEFCLASS) {
+                acc = acc + (grp + dgrp);
+                dgrp = mk3(0.0f, 0.0f, 0.0f);
+            } else {
+                acc = acc + grp;
+            }
+            grp = mk3(0.0f, 0.0f, 0.0f);
+        };
+        // Texture::scatter — texture.rs:45-57 — for a sphere hit given (a, b, c) = (p-c).z, (p-c).x, (p-c).y/r (sphere.rs:67-73), else (U, V)
+        auto texel_color = [&](float a, float b, float c, bool uv_given, float scale, uint32_t tex) -> f3 {
+            float U = a, V = b;
+            if (!uv_given) {
+                U = (1.0f + atan2_finite(a, b) * 0.31830988618379067f) * 0.5f;  // sphere.rs:70
+                V = acos_over_pi(c);                                             // sphere.rs:71
+            }
+            const DevTexInfo ti = P.tex_info[tex];
+            const int32_t icx = texture_cast(U, scale, ti.width_f), icy = texture_cast(V, scale, ti.height_f);
+            uint32_t txl, tyl;
+            if (__ballot((icx | icy) < 0) == 0ull) {  // the usual case (sphere coordinates in [0, 1], positive scale): no sign to carry
+                txl = texture_rem(uint32_t(icx), ti.width, ti.magic_w);
+                tyl = texture_rem(uint32_t(icy), ti.height, ti.magic_h);
+            } else {
+                txl = texture_wrap_signed(icx, ti.width, ti.magic_w);
+                tyl = texture_wrap_signed(icy, ti.height, ti.magic_h);
+            }
+            const uint32_t texel = P.texels[ti.first_texel + (((tyl >> 3) * ti.tiles_per_row + (txl >> 3)) << 6) + ((tyl & 7u) << 3) + (txl & 7u)];
+            return mk3(float(texel & 255u), float((texel >> 8) & 255u), float((texel >> 16) & 255u)) * (1.0f / 255.0f);
+        };
         // MODE_BVH + point lights: the direct term of the surface shade() found, one light at a time. Finds the next light that
         // can contribute, starts its shadow ray (the lane is then "parked": 2) or, after the last light, closes the term (0).
         uint32_t lit = 0;  // index + 1 of the light whose shadow ray this lane is tracing, 0 = none
@@ -959,9 +1025,13 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
         // Second part of shade(): the surface of the hit in `h` (or the sky), once the scene query has returned.
         // (sph: a compile-time flag — the scene holds spheres only)
         // prim: the ray is a primary ray, so T = 1 and the origin is the camera: x * 1.0f = x exactly, so T is left out)
-        auto surface = [&](auto sph, auto prim) -> int {
+        // bounced: the caller KNOWS that the ray is not a primary ray (bounce != 0)
+        // Returns 1 = the path ended (radiance handed over), 0 = it goes on, 3 (QUEUE) = it ended at a texture after a bounce and
+        // the caller has to queue the evaluation (sf.tu/tv/tw, sf.param, sf.r1 and T describe it).
+        auto surface = [&](auto sph, auto prim, auto bounced) -> int {
             constexpr bool SPH = decltype(sph)::value;
             constexpr bool PRIM = decltype(prim)::value;
+            constexpr bool BOUNCED = decltype(bounced)::value;
             bool done;
             if (h.shape == RT_NONE) {  // ray.rs:85, background_color ray.rs:89-93 (the direction is already unit)
                 // t = 0.5(d.y + 1); (1-t)(1,1,1) + t(0.5,0.7,1) = (1 - 0.5t, 1 - 0.3t, 1) = (0.75 - 0.25 d.y, 0.85 - 0.15 d.y, 1)
@@ -1024,32 +1094,25 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
                 if (sf.kind == RTHIP_MAT_TEXTURE) {
                     // Texture::scatter — texture.rs:45-57; bounce -> None (texture.rs:59-61) => path ends, ray.rs:80
                     RT_ARM_COUNT(2, 3)
-                    float U, V;
-                    if (SPH || h.shape < P.n_spheres) {
-                        U = (1.0f + atan2_finite(sf.tu, sf.tv) * 0.31830988618379067f) * 0.5f;  // sphere.rs:70
-                        V = acos_over_pi(sf.tw);                                             // sphere.rs:71
-                    } else if (h.shape < P.n_spheres + P.n_planes) {
-                        const uint32_t i = h.shape - P.n_spheres;
-                        const rt_f4 g1 = P.pln_geom[4 * i + 1], g2 = P.pln_geom[4 * i + 2], g3 = P.pln_geom[4 * i + 3];
-                        const f3 q = mk3(p.x - g1.x, p.y - g1.y, p.z - g1.z);
-                        U = dot(q, mk3(g2.x, g2.y, g2.z));
-                        V = dot(q, mk3(g3.x, g3.y, g3.z));
-                    } else {
-                        U = h.b1, V = h.b2;
+                    const bool defcls = DEFCLASS && !PRIM && (BOUNCED || bounce != 0u);
+                    if (!(SPH || h.shape < P.n_spheres)) {
+                        // (U, V) of a plane / triangle hit go where a sphere hit keeps (p-c).z, (p-c).x
+                        if (h.shape < P.n_spheres + P.n_planes) {
+                            const uint32_t i = h.shape - P.n_spheres;
+                            const rt_f4 g1 = P.pln_geom[4 * i + 1], g2 = P.pln_geom[4 * i + 2], g3 = P.pln_geom[4 * i + 3];
+                            const f3 q = mk3(p.x - g1.x, p.y - g1.y, p.z - g1.z);
+                            sf.tu = dot(q, mk3(g2.x, g2.y, g2.z));
+                            sf.tv = dot(q, mk3(g3.x, g3.y, g3.z));
+                        } else {
+                            sf.tu = h.b1, sf.tv = h.b2;
+                        }
                     }
-                    const DevTexInfo ti = P.tex_info[__float_as_uint(sf.r1)];  // a texture material's r1 slot holds its texture index
-                    const int32_t icx = texture_cast(U, sf.param, ti.width_f), icy = texture_cast(V, sf.param, ti.height_f);
-                    uint32_t txl, tyl;
-                    if (__ballot((icx | icy) < 0) == 0ull) {  // the usual case (sphere coordinates in [0, 1], positive scale): no sign to carry
-                        txl = texture_rem(uint32_t(icx), ti.width, ti.magic_w);
-                        tyl = texture_rem(uint32_t(icy), ti.height, ti.magic_h);
-                    } else {
-                        txl = texture_wrap_signed(icx, ti.width, ti.magic_w);
-                        tyl = texture_wrap_signed(icy, ti.height, ti.magic_h);
+                    if constexpr (QUEUE && !PRIM) {
+                        if (defcls) return 3;  // evaluated later, 64 at a time (the deferred texture queue)
                     }
-                    const uint32_t texel = P.texels[ti.first_texel + (((tyl >> 3) * ti.tiles_per_row + (txl >> 3)) << 6) + ((tyl & 7u) << 3) + (txl & 7u)];
-                    const f3 c = mk3(float(texel & 255u), float((texel >> 8) & 255u), float((texel >> 16) & 255u)) * (1.0f / 255.0f);
-                    emit(PRIM ? c : T * c);
+                    const f3 c = texel_color(sf.tu, sf.tv, sf.tw, !(SPH || h.shape < P.n_spheres), sf.param, __float_as_uint(sf.r1));  // a texture material's r1 slot holds its texture index
+                    if (defcls) emit_def(T * c);
+                    else emit(PRIM ? c : T * c);
                     done = true;
                 } else {
                     if (LIGHTS) {  // the mirror direction feeds the Phong term; without lights next_ray() computes it, and only for Metal / Dielectric
@@ -1098,7 +1161,7 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
             }
             return done ? 1 : 0;
         };
-        auto shade = [&](auto sph) -> int {
+        auto shade = [&](auto sph, auto bounced) -> int {
             constexpr bool SPH = decltype(sph)::value;
             if (dead) {  // None -> new_color alone, ray.rs:80
                 dead = false;
@@ -1138,7 +1201,7 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
                     cnt[RT_STAT_RAYS]++;
                 }
             }
-            return surface(sph, std::integral_constant<bool, false>{});
+            return surface(sph, std::integral_constant<bool, false>{}, bounced);
         };
         // Second half: the lane's next ray — the scattered ray of the surface shade() left behind, or
         // (fresh) the primary ray of a new sample. Both need one RNG pair and one normalisation; sharing
@@ -1302,120 +1365,279 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
                     cnt[RT_STAT_PATHS] += n_spp;
                     cnt[RT_STAT_RAYS] += n_spp;
                 }
-            } else if (RT_PRIMARY_INLINE && primary_inline) {
+            } else {
+            // ---- deferred texture queue (QUEUE) -------------------------------------------------------------------------------
+            // A bounce ray that ends at a texture (terminal: texture.rs:59-61) needs the 105-instruction Texture::scatter arm, and
+            // on a ground tile a handful of lanes want it in every other iteration: the arm ran at 8 % lane utilisation and was a
+            // quarter of the tile's instructions. Here such a lane only QUEUES the evaluation — 9 dwords in LDS: T, the sphere
+            // coordinates (or U, V), scale, texture, the parity of its sample group — and starts its next sample; when the
+            // queue would overflow the wave runs the arm ONCE for its (up to) 64 entries, every lane on another entry, and
+            // each lane then takes its own results, in the order it queued them (= the order of its samples), into the deferred
+            // sum of the group they belong to. g_k = grp_k + def_k as everywhere (DEFCLASS): same numbers, same order, same bits
+            // as the variants that evaluate at once. Two groups can be in flight per lane (entries of the group it has just left
+            // may still wait): def[2]; a group that is left while entries of it wait is parked in `closed` and folded at the
+            // next flush, and a flush is forced before entries get 48 iterations old, i.e. long before that lane can leave its
+            // next group (a group is >= 64 samples, a lane ends at most one sample per iteration).
+            uint32_t q_count = 0, q_age = 0;  // wave-uniform: entries waiting; iterations since the queue was last empty
+            uint32_t qstate = 0;              // per lane: entries waiting of group parity 0 | parity 1 << 8 | a closed group waits << 16 | its parity << 17
+            uint32_t *q_ent = (uint32_t *)s_dyn + lwave * RT_QUEUE_WAVE_DWORDS;  // [9][64]
+            unsigned long long *q_mask = (unsigned long long *)(q_ent + 576);      // [64]: the entries of lane l
+            float *q_def = (float *)(q_ent + 704);                                  // [2][3][64]
+            float *q_closed = q_def + 384;                                          // [3][64]
+            const uint32_t g_mask = P.slice_spp - 1u;  // slice_spp is a power of two
+            const uint32_t g_shift = 31u - uint32_t(__builtin_clz(P.slice_spp));
+            if constexpr (QUEUE) {
+                q_mask[lane] = 0ull;
+#pragma unroll
+                for (uint32_t i = 0; i < 6u; i++) q_def[i * 64u + lane] = 0.0f;
+            }
+            // runs the arm for every queued entry and hands the results to their lanes; called by all lanes of the loop together
+            // (the stages are kept apart — "memory" — so that an entry's fields are read when they are needed, not all up front:
+            // the whole path state of the lanes is live here, and the arm's temporaries are what would spill)
+            auto q_flush = [&]() {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long ex = __ballot(true);
+                const uint32_t step = uint32_t(__popcll(ex));
+                for (uint32_t e = wave_prefix(ex); e < q_count; e += step) {
+                    f3 c = texel_color(__uint_as_float(q_ent[192u + e]), __uint_as_float(q_ent[256u + e]), __uint_as_float(q_ent[320u + e]),
+                                       !SPH_SCENE && (q_ent[512u + e] & 2u) != 0u, __uint_as_float(q_ent[384u + e]), q_ent[448u + e]);
+                    asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z) : : "memory");
+                    const f3 L = mk3(__uint_as_float(q_ent[e]), __uint_as_float(q_ent[64u + e]), __uint_as_float(q_ent[128u + e])) * c;
+                    q_ent[e] = __float_as_uint(L.x), q_ent[64u + e] = __float_as_uint(L.y), q_ent[128u + e] = __float_as_uint(L.z);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // every lane adds its own results to the deferred sum of their group, in queue order (LDS operations of a lane
+                // execute in program order; nobody else touches the lane's sums)
+                for (unsigned long long m = q_mask[lane]; m != 0ull; m &= m - 1ull) {
+                    const uint32_t e = uint32_t(__builtin_ctzll(m));
+                    float *d = q_def + (q_ent[512u + e] & 1u) * 192u + lane;
+                    atomicAdd(d, __uint_as_float(q_ent[e]));
+                    atomicAdd(d + 64, __uint_as_float(q_ent[64u + e]));
+                    atomicAdd(d + 128, __uint_as_float(q_ent[128u + e]));
+                }
+                q_mask[lane] = 0ull;
+                if (qstate & 0x10000u) {  // the group this lane left while entries of it waited: now it is complete
+                    const uint32_t o = ((qstate >> 17) & 1u) * 192u + lane;
+                    const f3 cg = mk3(q_closed[lane], q_closed[64u + lane], q_closed[128u + lane]);
+                    const f3 d = mk3(q_def[o], q_def[64u + o], q_def[128u + o]);
+                    acc = acc + (cg + d);
+                    q_def[o] = 0.0f, q_def[64u + o] = 0.0f, q_def[128u + o] = 0.0f;
+                }
+                qstate = 0u;
+                q_count = 0u, q_age = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            };
+            // Once per loop iteration, all lanes together. push: this lane's path has just ended at a texture (surface() returned 3);
+            // par: the parity of that sample's group; drain: every lane has traced its last sample — empty the queue.
+            // Returns true when the loop may end (drain, and nothing waits).
+            auto q_step = [&](bool push, uint32_t par, bool drain) -> bool {
+                const unsigned long long pm = __ballot(push);
+                const uint32_t n = uint32_t(__popcll(pm));
+                if (q_count != 0u) q_age++;
+                // ONE flush site (the arm is a hundred instructions: one copy per loop): before the push when the new entries would not fit
+                const bool full = q_count + n > 64u;
+                if (q_count != 0u && (full || q_age >= 48u || (drain && n == 0u))) q_flush();
+                if (pm != 0ull) {
+                    if (push) {
+                        const uint32_t e = q_count + wave_prefix(pm);
+                        const bool uv = !SPH_SCENE && !(h.shape < P.n_spheres);
+                        q_ent[e] = __float_as_uint(T.x), q_ent[64u + e] = __float_as_uint(T.y), q_ent[128u + e] = __float_as_uint(T.z);
+                        q_ent[192u + e] = __float_as_uint(sf.tu), q_ent[256u + e] = __float_as_uint(sf.tv), q_ent[320u + e] = __float_as_uint(sf.tw);
+                        q_ent[384u + e] = __float_as_uint(sf.param), q_ent[448u + e] = __float_as_uint(sf.r1);
+                        q_ent[512u + e] = par | (uv ? 2u : 0u);
+                        q_mask[lane] |= 1ull << e;
+                        qstate += par ? 0x100u : 1u;
+                    }
+                    q_count += n;
+                }
+                return drain && q_count == 0u;
+            };
+            // a lane has finished sample number s_done (1-based) of its n_spp: group boundary?
+            auto q_account = [&](uint32_t s_done) {
+                if ((s_done & g_mask) == 0u && s_done != n_spp) {
+                    const uint32_t par = ((s_done - 1u) >> g_shift) & 1u;
+                    const uint32_t o = par * 192u + lane;
+                    if (((qstate >> (par * 8u)) & 0xffu) == 0u) {
+                        const f3 d = mk3(q_def[o], q_def[64u + o], q_def[128u + o]);
+                        acc = acc + (grp + d);
+                        q_def[o] = 0.0f, q_def[64u + o] = 0.0f, q_def[128u + o] = 0.0f;
+                    } else {
+                        q_closed[lane] = grp.x, q_closed[64u + lane] = grp.y, q_closed[128u + lane] = grp.z;
+                        qstate |= 0x10000u | (par << 17);
+                    }
+                    grp = mk3(0.0f, 0.0f, 0.0f);
+                }
+            };
+            // after the loop: whatever still waits, then the lane's last group
+            auto q_finish = [&]() {
+                const uint32_t o = (((n_spp - 1u) >> g_shift) & 1u) * 192u + lane;
+                const f3 d = mk3(q_def[o], q_def[64u + o], q_def[128u + o]);
+                acc = acc + (grp + d);
+            };
+            // ---- the primary ray of a fresh sample, inline (see below); returns true if the path ended there
+            const __attribute__((address_space(3))) lds_f4 *prim_lds = (const __attribute__((address_space(3))) lds_f4 *)(s_shade_mem + RT_SHADE_RECS * P.n_spheres);
+            auto primary_fresh = [&]() -> bool {
+                // next_ray(true) without the state a primary ray does not need (origin = camera, T = 1, no shape to start on)
+                key = key_own;
+                key_own += RT_RNG_SLOTS * RT_RNG_GOLDEN;
+                const uint32_t hb = rt_mix32(key);
+                const float ua = rt_unit(hb), ub = rt_unit(rt_second(hb));
+                set_dir(mk3(fmaf(vh_v.x, ub, fmaf(hw_v.x, ua, pp_own.x)), fmaf(vh_v.y, ub, fmaf(hw_v.y, ua, pp_own.y)),
+                            fmaf(vh_v.z, ub, fmaf(hw_v.z, ua, pp_own.z))));
+                asm volatile("v_mov_b32 %0, 0" : "+v"(bounce));
+                if (LIGHTS) {  // the direct-light code of surface() reads T and the origin: no shortcut for them
+                    Ld = mk3(0.0f, 0.0f, 0.0f);
+                    asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.x) : "v"(cam_v.x));
+                    asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.y) : "v"(cam_v.y));
+                    asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.z) : "v"(cam_v.z));
+                    asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.x));
+                    asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.y));
+                    asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.z));
+                }
+                float nbest = -__uint_as_float(__float_as_uint(r.tmax) - 1u);
+                const float ntmin = -r.tmin;
+                h.shape = RT_NONE;
+                for (unsigned long long m = pmask; m != 0ull; m &= m - 1ull) {
+                    const uint32_t i = uint32_t(__builtin_ctzll(m));  // wave-uniform: broadcast read
+                    const lds_f4 pv = prim_lds[i];                    // {camera - centre, |camera - centre|^2 - r^2}
+                    const float half_b = dot(mk3(pv.x, pv.y, pv.z), r.d);
+                    const float disc = fmaf(half_b, half_b, -pv.w);
+                    const float root = fast_sqrt(disc);
+                    const float n0 = half_b + root, n1 = half_b - root;
+                    const float n = (n0 < ntmin) ? n0 : n1;
+                    const bool take = (n1 < ntmin) & !(n < nbest);
+                    nbest = take ? n : nbest;
+                    h.shape = take ? i : h.shape;
+                }
+                h.t = -nbest;
+                if (!SPH_SCENE) {  // ... then the planes and triangles, as closest_hit() goes on over them (the ray starts at the camera)
+                    Ray pr = r;
+                    pr.o = cam_v;
+                    for (uint32_t i = 0; i < P.n_planes; i++) {
+                        float t;
+                        bool ok = hit_plane(P.pln_geom[4 * i], pr, t);
+                        RT_TAKE(ok, t, P.n_spheres + i, (void)0)
+                    }
+                    tris_closest(P, pr, h);
+                }
+                cnt[RT_STAT_RAYS]++;
+                return surface(scene_sph, std::integral_constant<bool, !LIGHTS>{}, std::integral_constant<bool, false>{}) != 0;
+            };
+            constexpr std::integral_constant<bool, true> is_bounced{};
+            constexpr std::integral_constant<bool, false> maybe_primary{};
+            if (RT_PRIMARY_INLINE && primary_inline) {
                 // ---- lane = pixel, primary ray inline: a fresh sample traces its primary ray at once, against the spheres of pmask
                 // only, and joins the other lanes' scattered rays in the same iteration. Where most paths are "ground, then sky"
                 // a path then costs one full scan instead of two. The skipped spheres cannot be hit (the cone test above), the
                 // others are tested in index order with the expressions of closest_hit(): same hit, same bits.
                 if (active) {
                     uint32_t s_done = 0;
-                    const uint32_t g_mask = P.slice_spp - 1u;
-                    const __attribute__((address_space(3))) lds_f4 *prim_lds = (const __attribute__((address_space(3))) lds_f4 *)(s_shade_mem + RT_SHADE_RECS * P.n_spheres);
                     bool fresh = true;
-                    for (;;) {
-                        bool ended = false;
-#ifdef RT_CLASS_CYCLES
-                        {
-                            const unsigned long long ex = __ballot(true);
-                            if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex), 0u)) == 0) cnt[RT_STAT_NODE] += 64;
-                            cnt[RT_STAT_SKY]++;
-                            cnt[RT_STAT_SHADOW] += fresh ? 1u : 0u;
-                        }
-#endif
-                        if (fresh) {
-                            // next_ray(true) without the state a primary ray does not need (origin = camera, T = 1, no shape to start on)
-                            key = key_own;
-                            key_own += RT_RNG_SLOTS * RT_RNG_GOLDEN;
-                            const uint32_t hb = rt_mix32(key);
-                            const float ua = rt_unit(hb), ub = rt_unit(rt_second(hb));
-                            set_dir(mk3(fmaf(vh_v.x, ub, fmaf(hw_v.x, ua, pp_own.x)), fmaf(vh_v.y, ub, fmaf(hw_v.y, ua, pp_own.y)),
-                                        fmaf(vh_v.z, ub, fmaf(hw_v.z, ua, pp_own.z))));
-                            asm volatile("v_mov_b32 %0, 0" : "+v"(bounce));
-                            if (LIGHTS) {  // the direct-light code of surface() reads T and the origin: no shortcut for them
-                                Ld = mk3(0.0f, 0.0f, 0.0f);
-                                asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.x) : "v"(cam_v.x));
-                                asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.y) : "v"(cam_v.y));
-                                asm volatile("v_mov_b32 %0, %1" : "+v"(r.o.z) : "v"(cam_v.z));
-                                asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.x));
-                                asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.y));
-                                asm volatile("v_mov_b32 %0, 1.0" : "+v"(T.z));
-                            }
-                            float nbest = -__uint_as_float(__float_as_uint(r.tmax) - 1u);
-                            const float ntmin = -r.tmin;
-                            h.shape = RT_NONE;
-                            for (unsigned long long m = pmask; m != 0ull; m &= m - 1ull) {
-                                const uint32_t i = uint32_t(__builtin_ctzll(m));  // wave-uniform: broadcast read
-                                const lds_f4 pv = prim_lds[i];                    // {camera - centre, |camera - centre|^2 - r^2}
-                                const float half_b = dot(mk3(pv.x, pv.y, pv.z), r.d);
-                                const float disc = fmaf(half_b, half_b, -pv.w);
-                                const float root = fast_sqrt(disc);
-                                const float n0 = half_b + root, n1 = half_b - root;
-                                const float n = (n0 < ntmin) ? n0 : n1;
-                                const bool take = (n1 < ntmin) & !(n < nbest);
-                                nbest = take ? n : nbest;
-                                h.shape = take ? i : h.shape;
-                            }
-                            h.t = -nbest;
-                            if (!SPH_SCENE) {  // ... then the planes and triangles, as closest_hit() goes on over them (the ray starts at the camera)
-                                Ray pr = r;
-                                pr.o = cam_v;
-                                for (uint32_t i = 0; i < P.n_planes; i++) {
-                                    float t;
-                                    bool ok = hit_plane(P.pln_geom[4 * i], pr, t);
-                                    RT_TAKE(ok, t, P.n_spheres + i, (void)0)
+                    if constexpr (QUEUE) {
+                        // (a lane that has traced its last sample stays in the loop, idle, until every lane has: the queue is flushed by
+                        // all lanes together, and the last entries are evaluated after the loop)
+                        bool finished = false;
+                        for (;;) {
+                            int st = 0;
+                            if (!finished) {
+                                bool ended = false;
+                                if (fresh) ended = primary_fresh();
+                                st = 1;
+                                if (!ended) {
+                                    next_ray(false, 0, 0);
+                                    st = shade(scene_sph, is_bounced);
                                 }
-                                tris_closest(P, pr, h);
                             }
-                            cnt[RT_STAT_RAYS]++;
-                            ended = surface(scene_sph, std::integral_constant<bool, !LIGHTS>{}) != 0;
+                            const uint32_t par = (s_done >> g_shift) & 1u;
+                            if (!finished) {
+                                fresh = st != 0;
+                                if (fresh) {
+                                    s_done++;
+                                    finished = s_done == n_spp;
+                                }
+                            }
+                            if (q_step(st == 3, par, __ballot(!finished) == 0ull)) break;
+                            if (st != 0) q_account(s_done);
+                        }
+                        q_finish();
+                    } else {
+                        for (;;) {
+                            bool ended = false;
 #ifdef RT_CLASS_CYCLES
-                            cnt[RT_STAT_HIT0 + 3] += ended ? 1u : 0u;
+                            {
+                                const unsigned long long ex = __ballot(true);
+                                if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex), 0u)) == 0) cnt[RT_STAT_NODE] += 64;
+                                cnt[RT_STAT_SKY]++;
+                                cnt[RT_STAT_SHADOW] += fresh ? 1u : 0u;
+                            }
 #endif
-                        }
-                        if (!ended) {
-                            next_ray(false, 0, 0);
-                            fresh = shade(scene_sph) != 0;
-                        } else {
-                            fresh = true;
-                        }
-                        if (fresh) {
-                            s_done++;
-                            if (s_done == n_spp) break;
-                            if ((s_done & g_mask) == 0u) {
-                                acc = acc + grp;
-                                grp = mk3(0.0f, 0.0f, 0.0f);
+                            if (fresh) {
+                                ended = primary_fresh();
+#ifdef RT_CLASS_CYCLES
+                                cnt[RT_STAT_HIT0 + 3] += ended ? 1u : 0u;
+#endif
+                            }
+                            if (!ended) {
+                                next_ray(false, 0, 0);
+                                fresh = shade(scene_sph, is_bounced) != 0;
+                            } else {
+                                fresh = true;
+                            }
+                            if (fresh) {
+                                s_done++;
+                                if (s_done == n_spp) break;
+                                if ((s_done & g_mask) == 0u) fold();
                             }
                         }
+                        fold();
                     }
-                    acc = acc + grp;
                     cnt[RT_STAT_PATHS] += s_done;
                 }
             } else
             // ---- lane = pixel: path regeneration over the pixel's samples ----
             if (active) {
                 uint32_t s_done = 0;
-                const uint32_t g_mask = P.slice_spp - 1u;  // slice_spp is a power of two
                 next_ray(true, lane, 0);
-                for (;;) {
-#ifdef RT_BVH_DEBUG_UTIL
-                    if (STATS) {  // wave iterations x 64 (vs `rays` = lane iterations): the lanes a wave idles at its end
-                        const unsigned long long ex = __ballot(true);
-                        if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex), 0u)) == 0) cnt[RT_STAT_SHADOW] += 64;
-                    }
-#endif
-                    const bool fresh = shade(scene_sph) != 0;
-                    if (fresh) {
-                        s_done++;
-                        if (s_done == n_spp) break;
-                        if ((s_done & g_mask) == 0u) {
-                            acc = acc + grp;
-                            grp = mk3(0.0f, 0.0f, 0.0f);
+                if constexpr (QUEUE) {
+                    bool finished = false;
+                    for (;;) {
+                        int st = 0;
+                        if (!finished) st = shade(scene_sph, maybe_primary);
+                        const uint32_t par = (s_done >> g_shift) & 1u;
+                        const bool was_finished = finished;
+                        if (st != 0) {
+                            s_done++;
+                            finished = s_done == n_spp;
                         }
+                        if (q_step(st == 3, par, __ballot(!finished) == 0ull)) break;
+                        if (st != 0) q_account(s_done);
+                        if (!finished) next_ray(st != 0, lane, 0);
+                        (void)was_finished;
                     }
-                    next_ray(fresh, lane, 0);
+                    q_finish();
+                } else {
+                    for (;;) {
+#ifdef RT_BVH_DEBUG_UTIL
+                        if (STATS) {  // wave iterations x 64 (vs `rays` = lane iterations): the lanes a wave idles at its end
+                            const unsigned long long ex = __ballot(true);
+                            if (__builtin_amdgcn_mbcnt_hi(uint32_t(ex >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(ex), 0u)) == 0) cnt[RT_STAT_SHADOW] += 64;
+                        }
+#endif
+                        const bool fresh = shade(scene_sph, maybe_primary) != 0;
+                        if (fresh) {
+                            s_done++;
+                            if (s_done == n_spp) break;
+                            if ((s_done & g_mask) == 0u) fold();
+                        }
+                        next_ray(fresh, lane, 0);
+                    }
+                    fold();
                 }
-                acc = acc + grp;
                 cnt[RT_STAT_PATHS] += s_done;
+            }
             }
 #ifdef RT_CLASS_CYCLES
 #ifndef RT_ARM_COUNTS
@@ -1431,7 +1653,7 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
             // path has ended, and items are handed out up to `rows` rows ahead of it — the wave idles lanes for the slowest
             // paths only at the very end of its samples, not once per group of rows.
             const uint32_t rows = P.ring_rows, total = n_spp << 6, expect = uint32_t(__popcll(amask));
-            if (lane < 16u) s_rows[lane] = 0u;  // paths that have ended, per ring slot
+            if (lane < 16u) s_rows[lane] = 0u, s_rowdef[lane] = 0ull;  // paths that have ended, per ring slot
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             uint32_t next = 0;      // first item not yet handed out (wave-uniform)
@@ -1471,23 +1693,21 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
                     tracing = true;
                     return 3;
                 }
-                return surface(scene_sph, std::integral_constant<bool, false>{});
+                return surface(scene_sph, std::integral_constant<bool, false>{}, std::integral_constant<bool, false>{});
             };
             for (;;) {
                 // ---- retire the rows whose paths have all ended ----
                 while (oldest < n_spp && uint32_t(__builtin_amdgcn_readfirstlane(int(s_rows[oldest & (rows - 1u)]))) == expect) {
                     const uint32_t k = ((oldest & (rows - 1u)) << 6) + lane;
+                    const unsigned long long defrow = DEFCLASS ? s_rowdef[oldest & (rows - 1u)] : 0ull;
                     if (active) {
-                        grp.x += s_L[k];
-                        grp.y += s_L[plane + k];
-                        grp.z += s_L[2u * plane + k];
+                        const f3 L = mk3(s_L[k], s_L[plane + k], s_L[2u * plane + k]);
+                        if (DEFCLASS && ((defrow >> lane) & 1ull)) dgrp = dgrp + L;
+                        else grp = grp + L;
                     }
-                    if (lane == 0u) s_rows[oldest & (rows - 1u)] = 0u;
+                    if (lane == 0u) s_rows[oldest & (rows - 1u)] = 0u, s_rowdef[oldest & (rows - 1u)] = 0ull;
                     oldest++;
-                    if (oldest % P.slice_spp == 0u || oldest == n_spp) {
-                        acc = acc + grp;
-                        grp = mk3(0.0f, 0.0f, 0.0f);
-                    }
+                    if (oldest % P.slice_spp == 0u || oldest == n_spp) fold();
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -1531,7 +1751,7 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
                     }
                 }
                 if (have) {
-                    const int st = shade(scene_sph);
+                    const int st = shade(scene_sph, std::integral_constant<bool, false>{});
                     if (st == 1) {
                         cnt[RT_STAT_PATHS]++;
                         have = false;
@@ -1688,9 +1908,6 @@ extern "C" hipError_t rt_launch_compact(const KernelParams *P, uint32_t *list, u
 // two children of the i-th node of the current level, survivors are appended with ballot + prefix count — collects the leaves
 // it touches (at most RT_PRE_COLLECT), ranks them by (near, reference), keeps the RT_PRE_LEAVES nearest, and every lane
 // (pixel) marks the kept leaves its own pyramid touches and the nearest dropped one. Host mirror: rt_prepass_host.cpp.
-__device__ __forceinline__ uint32_t wave_prefix(unsigned long long m) {
-    return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-}
 __global__ __launch_bounds__(256) void prepass_kernel(const KernelParams P, RtTilePre *__restrict__ out) {
     __shared__ uint32_t s_front[4][2][RT_PRE_FRONT];
     __shared__ uint32_t s_ref[4][RT_PRE_COLLECT];
@@ -1897,12 +2114,18 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
         P.bvh_top_nodes = top;
         // per wave: stack levels x 64 lanes, 64 x {RNG key, x | y << 16}, 3 colour planes x ring rows x 64 radiance slots, 16 row counters
         const uint32_t waves = RT_WG_THREADS(MODE_BVH) / 64u;
-        lds = waves * (P.bvh_levels * 256u + 512u + 3u * 64u * 4u * P.ring_rows + 16u * 4u) + top * 32u;
+        lds = waves * (P.bvh_levels * 256u + 512u + 3u * 64u * 4u * P.ring_rows + 16u * 4u + 16u * 8u) + top * 32u;
     } else {
         P.ring_rows = 1;  // lane = pixel: no radiance slots
         P.bvh_levels = 0;
         P.bvh_top_nodes = 0;
-        lds = (mode == MODE_LDS) ? (RT_LDS_SPHERES + RT_SHADE_RECS * P.n_spheres + RT_PRIMARY_SPHERES) * 16u : 16u;
+        // (the variant with the deferred texture queue: the queues first, then geometry sized by the scene — see render_kernel)
+        const bool queue = RT_TEX_QUEUE != 0 && !count_stats && !lights;
+        const uint32_t n_padded = (P.n_spheres + RT_SCAN_UNROLL - 1u) & ~(RT_SCAN_UNROLL - 1u);
+        const uint32_t wg_waves = RT_WG_THREADS(MODE_LDS) / 64u;
+        if (mode != MODE_LDS) lds = 16u;
+        else if (queue) lds = wg_waves * RT_QUEUE_WAVE_DWORDS * 4u + (n_padded + RT_SHADE_RECS * P.n_spheres + RT_PRIMARY_SPHERES) * 16u;
+        else lds = (RT_LDS_SPHERES + RT_SHADE_RECS * P.n_spheres + RT_PRIMARY_SPHERES) * 16u;
     }
     if (lds > 65536u) return hipErrorInvalidValue;
     if (P.n_slices == 0 || P.slice_spp == 0 || (P.n_slices > 1 && (uint64_t(P.n_slices) * P.slice_spp < P.spp || !P.partial))) return hipErrorInvalidValue;
