@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RTHIP_ABI_VERSION 3
+#define RTHIP_ABI_VERSION 4
 
 typedef enum rthip_status {
     RTHIP_OK = 0,
@@ -232,8 +232,9 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *params, void 
                         void *hip_stream, rthip_stats *stats);
 
 /*
- * The same pass for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc). No counterpart in the reference. Calls no hipMalloc / hipFree / allocating routine:
+ * The same pass for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc; under HIP graph
+ * capture only for passes WITHOUT RTHIP_F_ACCUMULATE: the sample offset and 1/nb_samples are baked into the launch when it is
+ * captured, so a replayed graph re-traces the same samples — the same frame again, never a continued running sum). No counterpart in the reference. Calls no hipMalloc / hipFree / allocating routine:
  *   - the running sum lives in the CALLER's d_accum (required; owned_rows*width*3 floats): RTHIP_F_ACCUMULATE adds to what
  *     that buffer holds from the previous pass of this context (same buffer, same layout, else RTHIP_E_STATE);
  *   - the counter shards behind `stats` and the partial sums of a sample-sliced launch (spp > 64 on a launch of fewer than
@@ -311,11 +312,17 @@ enum {
 int rthip_group_create(const int *devices, int ndev, uint32_t flags, rthip_group **out_group);
 int rthip_group_upload_scene(rthip_group *group, const rthip_scene_desc *scene); /* rthip_upload_scene on every device */
 int rthip_group_set_camera(rthip_group *group, const rthip_camera *camera);
-/* One pass over the WHOLE frame. params: band_rows = rows per band (0 = 8), band_first / band_stride must be 0;
- * RTHIP_F_ADAPTIVE is not supported. rgba8_out: height*width*4 bytes, accum_out: height*width*3 floats (either may be NULL),
- * both host buffers, row 0 = bottom. stats (nullable): counters summed over devices, kernel_ms = the slowest device,
- * gather_ms. RTHIP_F_ACCUMULATE works as in rthip_render (every device keeps the running sum of its rows). */
+/* One pass over the WHOLE frame. params: band_rows = rows per band (0 = 8), band_first / band_stride must be 0.
+ * rgba8_out: height*width*4 bytes, accum_out: height*width*3 floats (either may be NULL), both host buffers, row 0 = bottom.
+ * stats (nullable): counters summed over devices, kernel_ms = the slowest device, gather_ms. RTHIP_F_ACCUMULATE works as in
+ * rthip_render (every device keeps the running sum of its rows), and so does RTHIP_F_ADAPTIVE — the progressive loop of
+ * standalone/src/main.rs:99-120 with the convergence rule of lib.rs:276-313 on N GPUs: every device keeps the PixelCache state
+ * and the work-list of its own rows.
+ * A frame that fails after its passes were enqueued (an RCCL or HIP error in the gather) leaves the group usable: the RCCL group
+ * call is always closed, every device is synchronised and every running sum is reset (the next frame starts over). */
 int rthip_group_render(rthip_group *group, const rthip_render_params *params, uint8_t *rgba8_out, float *accum_out, rthip_stats *stats);
+/* rthip_pixel_status for the whole frame of the last rthip_group_render (RTHIP_F_ADAPTIVE): height*width bytes each, rows in image order. */
+int rthip_group_pixel_status(rthip_group *group, uint8_t *status_out, uint8_t *same_color_count_out, uint64_t capacity_pixels);
 int rthip_group_reset_accum(rthip_group *group);
 int rthip_group_size(const rthip_group *group);
 rthip_ctx *rthip_group_context(rthip_group *group, int index); /* e.g. rthip_pick on device 0; owned by the group */

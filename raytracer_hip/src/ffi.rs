@@ -1,5 +1,5 @@
 //! #[repr(C)] mirrors of include/rthip.h and the extern "C" entry points. Keep in sync with the header
-//! (RTHIP_ABI_VERSION = 3); tests/test_abi.py pins the struct sizes the same way.
+//! (RTHIP_ABI_VERSION = 4); tests/test_abi.py pins the struct sizes the same way.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -13,6 +13,7 @@ pub const RTHIP_F_POINT_LIGHTS: u32 = 1 << 1;
 pub const RTHIP_F_COUNT_STATS: u32 = 1 << 2;
 pub const RTHIP_F_NO_BVH: u32 = 1 << 3;
 pub const RTHIP_F_ADAPTIVE: u32 = 1 << 4;
+pub const RTHIP_F_TILE_LISTS: u32 = 1 << 5;
 pub const RTHIP_STATUS_NOT_STARTED: u8 = 0;
 pub const RTHIP_STATUS_UNSTABLE: u8 = 2;
 pub const RTHIP_STATUS_FINAL: u8 = 3;
@@ -82,6 +83,7 @@ extern "C" {
     pub fn rthip_group_render(group: *mut rthip_group, params: *const rthip_render_params, rgba8_out: *mut u8, accum_out: *mut f32,
                               stats: *mut rthip_stats) -> c_int;
     pub fn rthip_group_reset_accum(group: *mut rthip_group) -> c_int;
+    pub fn rthip_group_pixel_status(group: *mut rthip_group, status_out: *mut u8, same_color_count_out: *mut u8, capacity_pixels: u64) -> c_int;
     pub fn rthip_group_size(group: *const rthip_group) -> c_int;
     pub fn rthip_group_context(group: *mut rthip_group, index: c_int) -> *mut rthip_ctx;
     pub fn rthip_group_last_error(group: *const rthip_group) -> *const c_char;

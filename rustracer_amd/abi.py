@@ -11,7 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # rthip_status
 OK, E_BADARG, E_HIP, E_OOM, E_NODEVICE, E_STATE, E_INTERNAL, E_RCCL = 0, -1, -2, -3, -4, -5, -6, -7
@@ -107,6 +107,7 @@ SYMBOLS = {
     "rthip_group_set_camera": (C.c_int, [C.c_void_p, _P(Camera)]),
     "rthip_group_render": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, _P(Stats)]),
     "rthip_group_reset_accum": (C.c_int, [C.c_void_p]),
+    "rthip_group_pixel_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "rthip_group_size": (C.c_int, [C.c_void_p]),
     "rthip_group_context": (C.c_void_p, [C.c_void_p, C.c_int]),
     "rthip_group_last_error": (C.c_char_p, [C.c_void_p]),

@@ -164,6 +164,10 @@ class Raytracer:
         the fields of a shape in place is not seen: call upload() again, or pass a fresh FlatScene.)"""
         if isinstance(scene, FlatScene):
             return None
+        if len(scene) > 4096:
+            # a list of a million shape objects: the full signature would cost more host time per frame than the frame's kernel.
+            # Cheap form: the length and the ends; pass big scenes as a FlatScene (or Mesh / SphereCloud objects), which skips this
+            return (len(scene), id(scene[0]), id(scene[-1]), tuple(id(l) for l in lights))
         return (tuple((id(sh), id(getattr(sh, "material", None))) for sh in scene), tuple(id(l) for l in lights))
 
     def _sync_scene_camera(self, scene, lights=()):
@@ -282,7 +286,15 @@ class GroupRaytracer:
     def invalidate_pixels(self):
         self._check(self._lib.rthip_group_reset_accum(self._grp))
 
-    def render(self, samples, max_depth=50, accumulate=False, flags=0, band_rows=8, want_accum=True, rgba_out=None) -> RenderResult:
+    def pixel_status(self):
+        """PixelColor.status / same_color_count of the whole last frame (adaptive passes), rows in image order."""
+        w, h = int(self.width), int(self.height)
+        status, count = np.empty((h, w), np.uint8), np.empty((h, w), np.uint8)
+        self._check(self._lib.rthip_group_pixel_status(self._grp, status.ctypes.data, count.ctypes.data, status.size))
+        return status, count
+
+    def render(self, samples, max_depth=50, accumulate=False, flags=0, band_rows=8, want_accum=True, rgba_out=None, adaptive=False) -> RenderResult:
+        flags |= abi.F_ADAPTIVE if adaptive else 0
         cam = self.camera.as_abi()
         key = bytes(cam)
         if key != self._uploaded_camera:

@@ -81,10 +81,72 @@ def test_group_errors():
     assert lib.rthip_group_set_camera(grp, C.byref(cam)) == 0
     p2 = make_params(64, 36, 1, band_rows=8, band_first=1, band_stride=2)
     assert lib.rthip_group_render(grp, C.byref(p2), out.ctypes.data, None, None) == abi.E_BADARG
-    p3 = make_params(64, 36, 1, flags=abi.F_ADAPTIVE)
-    assert lib.rthip_group_render(grp, C.byref(p3), out.ctypes.data, None, None) == abi.E_BADARG
+    st = np.zeros((36, 64), np.uint8)
+    assert lib.rthip_group_pixel_status(grp, st.ctypes.data, None, st.size) == abi.E_STATE   # no frame yet
     assert lib.rthip_group_render(grp, C.byref(p), out.ctypes.data, None, None) == 0, lib.rthip_group_last_error(grp)
     assert out[..., 3].min() == 255
     assert lib.rthip_group_context(grp, 0) and not lib.rthip_group_context(grp, 1)
     lib.rthip_group_destroy(grp)
     lib.rthip_group_destroy(None)
+
+
+def test_group_survives_a_failed_gather(standalone_flat):
+    """an error between ncclGroupStart and ncclGroupEnd must close the group, and a failed frame must leave the
+    devices' running sums consistent (reset). The failure is injected (rt_group_debug_fail_next: 1 = ncclSend gets a null
+    communicator inside the RCCL group, 2 = an error right after the passes were enqueued)."""
+    lib = abi.lib()
+    rt = Raytracer.new(160, 96, seed=4)
+    want = rt.render(standalone_flat, 3, max_depth=5)
+    rt.close()
+    for kw, what, status in (({"force_rccl": True}, 1, abi.E_RCCL), ({"force_rccl": True}, 2, abi.E_INTERNAL), ({"devices": (0, 0), "peer_copy": True}, 2, abi.E_INTERNAL)):
+        g = GroupRaytracer(160, 96, seed=4, **({"devices": (0,)} | kw))
+        g.upload(standalone_flat)
+        g.render(2, max_depth=5)                      # a running sum of 2 samples
+        lib.rt_group_debug_fail_next(g._grp, what)
+        with pytest.raises(abi.RthipError) as e:
+            g.render(1, max_depth=5, accumulate=True)
+        assert e.value.status == status and "reset" in str(e.value)
+        # the group still works (RCCL included), and the failed frame left no half-advanced running sum behind
+        got = g.render(3, max_depth=5, accumulate=True)
+        assert got.stats["nb_samples"] == 3
+        assert np.array_equal(got.rgba8, want.rgba8) and np.array_equal(got.accum, want.accum)
+        g.close()
+
+
+def test_group_adaptive_passes_equal_one_device(standalone_flat):
+    """RTHIP_F_ADAPTIVE across devices: the loop of standalone/src/main.rs:99-120 with the convergence rule
+    of lib.rs:276-313; every device keeps the PixelCache state of its rows. Frames and status maps equal the single-device ones."""
+    w, h, passes = 192, 104, 9
+    rt = Raytracer.new(w, h, seed=6)
+    one = []
+    for k in range(passes):
+        r = rt.render(standalone_flat, 1, max_depth=5, accumulate=k > 0, adaptive=True)
+        one.append((r.rgba8.copy(), r.accum.copy(), r.stats["pixels_traced"], r.stats["pixels_final"]))
+    st1, cnt1 = rt.pixel_status()
+    rt.close()
+    g = GroupRaytracer(w, h, seed=6, devices=(0, 0, 0), peer_copy=True)
+    g.upload(standalone_flat)
+    for k in range(passes):
+        r = g.render(1, max_depth=5, accumulate=k > 0, adaptive=True, flags=abi.F_COUNT_STATS if k == passes - 1 else 0)
+        assert np.array_equal(r.rgba8, one[k][0]) and np.array_equal(r.accum, one[k][1]), k
+        assert (r.stats["pixels_traced"], r.stats["pixels_final"]) == one[k][2:], k
+    st3, cnt3 = g.pixel_status()
+    assert np.array_equal(st3, st1) and np.array_equal(cnt3, cnt1)
+    assert (st1 == abi.STATUS_FINAL).any() and (st1 == abi.STATUS_UNSTABLE).any()
+    g.close()
+
+
+def test_group_rccl_between_two_devices(standalone_flat, whole):
+    """the product path of the group — RCCL send/recv between DISTINCT devices — against rthip_render, byte for byte.
+    Needs two GPUs: skipped on the one-GPU test box (until it has run somewhere, DESIGN.md calls that path unverified on hardware)."""
+    n = C.c_int(0)
+    assert abi.lib().rthip_device_count(C.byref(n)) == 0
+    if n.value < 2:
+        pytest.skip("needs two GPUs")
+    for devices in ((0, 1), tuple(range(n.value))):
+        g = GroupRaytracer(320, 181, seed=17, devices=devices)
+        g.upload(standalone_flat)
+        res = g.render(5, max_depth=6, flags=abi.F_COUNT_STATS, band_rows=8)
+        assert np.array_equal(res.rgba8, whole.rgba8) and np.array_equal(res.accum, whole.accum)
+        assert res.stats["rays"] == whole.stats["rays"]
+        g.close()
