@@ -248,6 +248,19 @@ int rthip_render_device(rthip_ctx *ctx, const rthip_render_params *params, void 
 int rthip_render_device_noalloc(rthip_ctx *ctx, const rthip_render_params *params, void *d_rgba8, void *d_accum,
                                 void *hip_stream, rthip_stats *stats);
 
+/*
+ * The same pass with the frame copy taken off the critical path, for the progressive window loop
+ * (standalone/src/main.rs:99-102: one pass of 1 spp per iteration, forever). Two frame slots: rthip_render_async enqueues the
+ * pass and the copy of its RGBA8 rows into rgba8_out (owned_rows*width*4 bytes; page-locked memory from rthip_host_alloc makes
+ * the copy asynchronous and 5x faster) and returns at once; rthip_wait(slot) returns when that frame is in rgba8_out.
+ * Alternating the slots, the copy of one pass runs beside the kernel of the next: a 4K 1-spp pass costs the copy (0.6 ms)
+ * instead of copy + kernel + two synchronisations. Passes execute in call order and may carry RTHIP_F_ACCUMULATE /
+ * RTHIP_F_ADAPTIVE; no counters. A slot holds one frame: RTHIP_E_STATE if it is started again before rthip_wait.
+ * rgba8_out must stay valid until rthip_wait; rthip_upload_scene / rthip_destroy wait for everything in flight.
+ */
+int rthip_render_async(rthip_ctx *ctx, const rthip_render_params *params, uint8_t *rgba8_out, uint32_t slot);
+int rthip_wait(rthip_ctx *ctx, uint32_t slot);
+
 /* Forget the running sum: PixelRenderer::invalidate_pixels / RandomGenerator::invalidate_pixels
  * (lib.rs:79,120-138). */
 int rthip_reset_accum(rthip_ctx *ctx);

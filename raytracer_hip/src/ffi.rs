@@ -89,6 +89,8 @@ extern "C" {
     pub fn rthip_group_last_error(group: *const rthip_group) -> *const c_char;
     pub fn rthip_group_destroy(group: *mut rthip_group);
     pub fn rthip_band_row_owner(band_rows: u32, ndev: u32, y: u32, out_rank: *mut u32, out_local_row: *mut u32) -> c_int;
+    pub fn rthip_render_async(ctx: *mut rthip_ctx, params: *const rthip_render_params, rgba8_out: *mut u8, slot: u32) -> c_int;
+    pub fn rthip_wait(ctx: *mut rthip_ctx, slot: u32) -> c_int;
     pub fn rthip_host_alloc(bytes: usize, out_ptr: *mut *mut c_void) -> c_int;
     pub fn rthip_host_free(ptr: *mut c_void) -> c_int;
     pub fn rthip_pick(ctx: *mut rthip_ctx, width: u32, height: u32, x: f64, y: f64, out_shape: *mut i64) -> c_int;

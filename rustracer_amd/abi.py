@@ -98,6 +98,8 @@ SYMBOLS = {
     "rthip_owned_rows": (C.c_int, [_P(RenderParams), _P(C.c_uint32)]),
     "rthip_render": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, _P(Stats)]),
     "rthip_render_device": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]),
+    "rthip_render_async": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_uint32]),
+    "rthip_wait": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rthip_reset_accum": (C.c_int, [C.c_void_p]),
     "rthip_render_device_noalloc": (C.c_int, [C.c_void_p, _P(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p, _P(Stats)]),
     "rthip_pixel_status": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),

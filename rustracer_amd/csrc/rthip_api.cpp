@@ -61,6 +61,11 @@ struct rthip_ctx {
     unsigned long long *stats_host = nullptr;  // page-locked landing buffer of the counter shards (no staging allocation per pass)
     void *scratch = nullptr;                   // this device's copy of the static scratch array (rthip_render_device_noalloc)
     const void *acc_buffer = nullptr;          // where the running sum lives: ctx->accum.p, or the caller's d_accum (no-alloc passes)
+    // rthip_render_async / rthip_wait: two frames in flight (the copy of one overlaps the pass of the next)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_rendered[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    DevBuf staging_async[2];
+    bool async_busy[2] = {false, false};
     const void *pre_lists = nullptr;           // the primary-visibility lists (rt_prepass.h) made for the running sum's frame, if any:
                                                // RTHIP_F_ACCUMULATE passes of the same frame reuse them (same camera, scene, layout)
 };
@@ -287,6 +292,15 @@ void rthip_destroy(rthip_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_last) (void)hipEventDestroy(ctx->ev_last);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    for (int i = 0; i < 2; i++) {
+        ctx->staging_async[i].release();
+        if (ctx->ev_rendered[i]) (void)hipEventDestroy(ctx->ev_rendered[i]);
+        if (ctx->ev_copied[i]) (void)hipEventDestroy(ctx->ev_copied[i]);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -800,6 +814,55 @@ int rthip_render(rthip_ctx *ctx, const rthip_render_params *p, uint8_t *rgba8_ou
     } catch (...) {
         return fail(ctx, RTHIP_E_INTERNAL, "unexpected exception in rthip_render");
     }
+}
+
+// The progressive window loop (standalone/src/main.rs:99-102) wants a frame per pass, and at 4K the copy of the frame (33 MB:
+// ~0.6 ms into page-locked memory) is four times the pass itself. So: two frame slots. rthip_render_async enqueues the pass of
+// a slot on the context's stream and the copy of its RGBA8 rows on a copy stream behind it, and returns; rthip_wait blocks
+// until that slot's frame is in the caller's buffer. With two slots alternating, the copy of pass k runs beside the kernel of
+// pass k+1 and a pass costs max(kernel, copy) instead of their sum. Passes run in call order (one stream); they may carry
+// RTHIP_F_ACCUMULATE / RTHIP_F_ADAPTIVE like any other pass. No counters (the read-out would serialise the loop).
+int rthip_render_async(rthip_ctx *ctx, const rthip_render_params *p, uint8_t *rgba8_out, uint32_t slot) {
+    if (!ctx) return RTHIP_E_BADARG;
+    try {
+        if (slot > 1) return fail(ctx, RTHIP_E_BADARG, "rthip_render_async: slot is 0 or 1");
+        if (!rgba8_out) return fail(ctx, RTHIP_E_BADARG, "rthip_render_async: rgba8_out is NULL");
+        if (ctx->async_busy[slot]) return fail(ctx, RTHIP_E_STATE, "rthip_render_async: the slot still holds a frame (rthip_wait first)");
+        int st = validate_params(ctx, p);
+        if (st) return st;
+        uint32_t rows = 0;
+        if ((st = owned_rows(p, &rows))) return fail(ctx, st, "bad band parameters");
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        if (!ctx->copy_stream) {
+            HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; i++) {
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_rendered[i], hipEventDisableTiming));
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_copied[i], hipEventDisableTiming));
+            }
+        }
+        const size_t bytes = size_t(rows) * p->width * 4;
+        if (bytes && (st = ensure(ctx, ctx->staging_async[slot], bytes))) return st;
+        st = rthip_render_device(ctx, p, bytes ? ctx->staging_async[slot].p : nullptr, nullptr, ctx->stream, nullptr);
+        if (st) return st;
+        HIPCHK(ctx, hipEventRecord(ctx->ev_rendered[slot], ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_rendered[slot], 0));
+        if (bytes) HIPCHK(ctx, hipMemcpyAsync(rgba8_out, ctx->staging_async[slot].p, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_copied[slot], ctx->copy_stream));
+        ctx->async_busy[slot] = true;
+        return RTHIP_OK;
+    } catch (...) {
+        return fail(ctx, RTHIP_E_INTERNAL, "unexpected exception in rthip_render_async");
+    }
+}
+
+int rthip_wait(rthip_ctx *ctx, uint32_t slot) {
+    if (!ctx) return RTHIP_E_BADARG;
+    if (slot > 1) return fail(ctx, RTHIP_E_BADARG, "rthip_wait: slot is 0 or 1");
+    if (!ctx->async_busy[slot]) return fail(ctx, RTHIP_E_STATE, "rthip_wait: no frame was started in this slot");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->async_busy[slot] = false;
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_copied[slot]));
+    return RTHIP_OK;
 }
 
 int rthip_host_alloc(size_t bytes, void **out_ptr) {

@@ -200,6 +200,17 @@ class Raytracer:
             renderer.set_image(rgba)
         return RenderResult(rgba, acc, st.as_dict())
 
+    def render_async(self, scene, samples, rgba_out, slot, max_depth=50, accumulate=False, adaptive=False, flags=0):
+        """rthip_render_async: start a pass whose frame lands in `rgba_out` (use host_array()); wait(slot) completes it."""
+        self._sync_scene_camera(scene)
+        fl = flags | (abi.F_ACCUMULATE if accumulate else 0) | (abi.F_ADAPTIVE if adaptive else 0)
+        p = make_params(int(self.width), int(self.height), samples, max_depth, self.seed, fl)
+        assert rgba_out.dtype == np.uint8 and rgba_out.flags.c_contiguous and rgba_out.nbytes == int(self.width) * int(self.height) * 4
+        _check(self._lib.rthip_render_async(self._ctx, C.byref(p), rgba_out.ctypes.data, int(slot)), self._ctx)
+
+    def wait(self, slot):
+        _check(self._lib.rthip_wait(self._ctx, int(slot)), self._ctx)
+
     def render_device(self, params: abi.RenderParams, d_rgba8=0, d_accum=0, stream=0, want_stats=False):
         """rthip_render_device with raw device pointers (ints), e.g. torch tensors' data_ptr()."""
         self._sync_scene_camera(None)

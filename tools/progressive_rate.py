@@ -18,3 +18,19 @@ for w, h in ((960, 540), (3840, 2160)):
         extra = f", {res.stats['pixels_final']} of {w * h} pixels Final after {n + 1} passes" if adaptive else ""
         print(f"{w}x{h} 1 spp/pass adaptive={adaptive}: {dt * 1e3:.3f} ms per pass wall ({1 / dt:.0f} passes/s), kernel {res.stats['kernel_ms']:.3f} ms, d2h {res.stats['d2h_ms']:.3f} ms{extra}")
         rt.close()
+
+# the same loop through rthip_render_async / rthip_wait: two frames in flight, the copy of pass k beside the kernel of pass k+1
+for w, h in ((960, 540), (3840, 2160)):
+    for adaptive in (False, True):
+        rt = Raytracer.new(w, h, seed=1)
+        frames = [host_array((h, w, 4), np.uint8), host_array((h, w, 4), np.uint8)]
+        rt.render_async(flat, 1, frames[0], 0, adaptive=adaptive)
+        n = 200
+        t0 = time.perf_counter()
+        for k in range(1, n + 1):
+            rt.render_async(flat, 1, frames[k & 1], k & 1, accumulate=True, adaptive=adaptive)
+            rt.wait((k - 1) & 1)  # frame k-1 is ready for the window while pass k runs
+        rt.wait(n & 1)
+        dt = (time.perf_counter() - t0) / n
+        print(f"{w}x{h} 1 spp/pass adaptive={adaptive} ASYNC: {dt * 1e3:.3f} ms per pass wall ({1 / dt:.0f} passes/s)")
+        rt.close()
