@@ -141,6 +141,10 @@ enum {
                                        becomes GenerationStatus::Final and is skipped by every later pass (lib.rs:277-279):
                                        no rays, running sum and colour unchanged. Passes after the first must also set
                                        RTHIP_F_ACCUMULATE; they trace a compacted work-list of the pixels not yet Final. */
+    RTHIP_F_COUNT_EXECUTED = 1u << 6, /* with RTHIP_F_COUNT_STATS: the instrumented kernel runs the production kernel's loops, so the counters
+                                       hold the shape tests actually EXECUTED (a primary ray is tested against the spheres its 8x8 tile can
+                                       reach, and not at all in tiles that see only sky) instead of the reference's scan over every shape
+                                       (ray.rs:47-67). Same image. For the "executed" roofline fraction beside the algorithmic one. */
     RTHIP_F_TILE_LISTS = 1u << 5    /* big scenes (BVH), experimental: primary rays test their pixel's primary-visibility list (one tree walk per
                                        8x8 tile, rt_prepass.h) instead of walking the tree themselves. Same image bit for bit; measured SLOWER
                                        than the plain traversal, kept for A/B runs and tests. Ignored without a tree. */

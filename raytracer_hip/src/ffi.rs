@@ -14,6 +14,7 @@ pub const RTHIP_F_COUNT_STATS: u32 = 1 << 2;
 pub const RTHIP_F_NO_BVH: u32 = 1 << 3;
 pub const RTHIP_F_ADAPTIVE: u32 = 1 << 4;
 pub const RTHIP_F_TILE_LISTS: u32 = 1 << 5;
+pub const RTHIP_F_COUNT_EXECUTED: u32 = 1 << 6;
 pub const RTHIP_STATUS_NOT_STARTED: u8 = 0;
 pub const RTHIP_STATUS_UNSTABLE: u8 = 2;
 pub const RTHIP_STATUS_FINAL: u8 = 3;

@@ -24,6 +24,7 @@ F_COUNT_STATS = 1 << 2
 F_NO_BVH = 1 << 3
 F_ADAPTIVE = 1 << 4
 F_TILE_LISTS = 1 << 5
+F_COUNT_EXECUTED = 1 << 6
 GROUP_F_PEER_COPY = 1 << 0
 GROUP_F_FORCE_RCCL = 1 << 1
 NOALLOC_SCRATCH_BYTES = 64 << 20

@@ -124,8 +124,11 @@ struct KernelParams {
     uint32_t spp, max_depth, seed, sample0, flags;
     uint32_t band_rows, band_first, band_stride, owned_rows;
     uint32_t accumulate;  // add the prior running sum (lib.rs:289-291)
+    uint32_t count_executed;  // RTHIP_F_COUNT_EXECUTED: the instrumented kernel takes the production kernel's loops (tests culled by them are not counted)
     // scene
     uint32_t n_spheres, n_planes, n_tris, n_lights, n_bvh_nodes;
+    uint32_t tree_scene;  // the scene has a tree, used or not (RTHIP_F_NO_BVH clears n_bvh_nodes): its linear scan is MODE_GLOBAL, which tests spheres
+                          // with the expressions of the tree's leaves (sphere_roots), so that tree == scan holds bit for bit
     uint32_t bvh_levels;  // traversal stack levels = depth of the tree
     uint32_t bvh_top_nodes;  // nodes [0, bvh_top_nodes) are the top of the tree in breadth-first order; the render kernel stages
                              // min(bvh_top_nodes, its LDS budget) of them in LDS (rt_launch_render)

@@ -39,6 +39,9 @@
 #include "rt_prepass.h"
 
 #define RT_NONE 0xffffffffu
+#ifndef RT_STABLE_SPHERE
+#define RT_STABLE_SPHERE 1
+#endif
 #ifndef RT_SCAN_UNROLL
 #define RT_SCAN_UNROLL 4u  /* MODE_LDS: spheres per group of the closest-hit scan; divides RT_LDS_SPHERES */
 #endif
@@ -94,9 +97,17 @@ struct HitRec {
 __device__ __forceinline__ void sphere_roots(rt_f4 g, const Ray &r, bool on_surface, float &n0, float &n1) {
     const f3 oc = mk3(r.o.x - g.x, r.o.y - g.y, r.o.z - g.z);
     const float half_b = dot(oc, r.d);
+#if RT_STABLE_SPHERE
+    // discriminant = r^2 - |oc - (oc.d) d|^2: the squared distance from the centre to the ray's line, taken from the vector itself.
+    // half_b^2 - (|oc|^2 - r^2) is the same number, but in FP32 its error is ~1e-7 |oc|^2 — for a sphere of radius 0.1 seen from
+    // 60 units away a tenth of a pixel of silhouette at 8K — where this form's is ~1e-7 r^2 ("hard parts").
+    const f3 l = fma3(r.d, -half_b, oc);
+    const float disc = on_surface ? half_b * half_b : g.w - dot(l, l);
+#else
     float c = fmaf(oc.z, oc.z, fmaf(oc.y, oc.y, fmaf(oc.x, oc.x, -g.w)));
     c = on_surface ? 0.0f : c;
     const float disc = fmaf(half_b, half_b, -c);
+#endif
     const float root = fast_sqrt(disc);  // NaN when disc < 0: every comparison on n0/n1 is then false
     n0 = half_b + root;
     n1 = half_b - root;
@@ -1309,7 +1320,7 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
             // (point lights change neither: a primary ray that reaches no shape gathers no light, and the cone test is about primary rays)
             // A few planes and triangles do not stand in the way of the primary-inline loop (it tests them all on every primary ray,
             // after the reachable spheres); the sky-only loop needs a scene of spheres.
-            if (!STATS && MODE == MODE_LDS && P.max_depth != 0 && n_spp >= RT_FAST_MIN_SPP && (SPH_SCENE || (P.n_planes <= RT_PRIMARY_TRIS && P.n_tris <= RT_PRIMARY_TRIS))) {
+            if ((!STATS || P.count_executed) && MODE == MODE_LDS && P.max_depth != 0 && n_spp >= RT_FAST_MIN_SPP && (SPH_SCENE || (P.n_planes <= RT_PRIMARY_TRIS && P.n_tris <= RT_PRIMARY_TRIS))) {
                 const f3 hw = mk3(P.hwx, P.hwy, P.hwz), vh = mk3(P.vhx, P.vhy, P.vhz);
                 const f3 e00 = mk3(pp_own.x, pp_own.y, pp_own.z), e10 = e00 + hw, e01 = e00 + vh, e11 = e10 + vh;
                 const f3 ec = e00 + (hw + vh) * 0.5f;
@@ -1364,6 +1375,7 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
                     acc = acc + grp;
                     cnt[RT_STAT_PATHS] += n_spp;
                     cnt[RT_STAT_RAYS] += n_spp;
+                    if (STATS) cnt[RT_STAT_SKY] += n_spp;  // (RTHIP_F_COUNT_EXECUTED: no shape test is executed here)
                 }
             } else {
             // ---- deferred texture queue (QUEUE) -------------------------------------------------------------------------------
@@ -1524,6 +1536,10 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
                     tris_closest(P, pr, h);
                 }
                 cnt[RT_STAT_RAYS]++;
+                if (STATS) {  // RTHIP_F_COUNT_EXECUTED: the tests this loop actually makes (the reachable spheres only)
+                    cnt[RT_STAT_SPHERE] += uint32_t(__popcll(pmask));
+                    if (!SPH_SCENE) cnt[RT_STAT_PLANE] += P.n_planes, cnt[RT_STAT_TRI] += P.n_tris;
+                }
                 return surface(scene_sph, std::integral_constant<bool, !LIGHTS>{}, std::integral_constant<bool, false>{}) != 0;
             };
             constexpr std::integral_constant<bool, true> is_bounced{};
@@ -2096,7 +2112,7 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
     if (P.worklist) blocks = uint32_t((uint64_t(P.owned_rows) * P.width + 255u) / 256u);  // worst case: nothing is Final yet
     if (blocks == 0 || P.spp == 0) return hipSuccess;
     const bool lights = (P.flags & RTHIP_F_POINT_LIGHTS) && P.n_lights > 0;
-    const int mode = P.n_bvh_nodes > 0 ? MODE_BVH : (P.n_spheres <= RT_LDS_SPHERES ? MODE_LDS : MODE_GLOBAL);
+    const int mode = P.n_bvh_nodes > 0 ? MODE_BVH : ((P.n_spheres <= RT_LDS_SPHERES && !P.tree_scene) ? MODE_LDS : MODE_GLOBAL);
     uint32_t lds = 0;
     if (mode == MODE_BVH) {
         if (P.bvh_levels == 0 || P.bvh_levels > RT_BVH_MAX_DEPTH) return hipErrorInvalidValue;

@@ -158,7 +158,7 @@ int validate_params(rthip_ctx *ctx, const rthip_render_params *p) {
     // the RNG counter of a sample has 256 slots: slot 0 = pixel jitter, slot 1 + bounce = the material draws of that segment (rt_rng.h)
     if (p->max_depth > 255) return fail(ctx, RTHIP_E_BADARG, "max_depth above 255 is not supported (a deeper path would reuse the random numbers of the pixel's next sample)");
     if (p->band_rows != 0 && p->band_stride == 0) return fail(ctx, RTHIP_E_BADARG, "band_stride must be >= 1 when band_rows != 0");
-    if (p->flags & ~uint32_t(RTHIP_F_ACCUMULATE | RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_NO_BVH | RTHIP_F_ADAPTIVE | RTHIP_F_TILE_LISTS))
+    if (p->flags & ~uint32_t(RTHIP_F_ACCUMULATE | RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_NO_BVH | RTHIP_F_ADAPTIVE | RTHIP_F_TILE_LISTS | RTHIP_F_COUNT_EXECUTED))
         return fail(ctx, RTHIP_E_BADARG, "unknown flag bits");
     for (int i = 0; i < 7; i++)
         if (p->reserved[i] != 0) return fail(ctx, RTHIP_E_BADARG, "reserved fields must be 0");
@@ -639,6 +639,7 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         k.flags = p->flags;
         k.band_rows = p->band_rows, k.band_first = p->band_first, k.band_stride = p->band_stride, k.owned_rows = rows;
         k.accumulate = accumulate ? 1u : 0u;
+        k.count_executed = (p->flags & RTHIP_F_COUNT_EXECUTED) ? 1u : 0u;
         k.inv_nb = float(1.0 / double(prior + p->spp));
         k.accum = noalloc ? (float *)d_accum : (float *)ctx->accum.p;
         k.accum_out = noalloc ? nullptr : (float *)d_accum;
@@ -646,6 +647,7 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         unsigned char *scratch = (unsigned char *)ctx->scratch;  // the device address from hipGetSymbolAddress, never the array's name
         unsigned long long *d_stats = noalloc ? (unsigned long long *)scratch : (unsigned long long *)ctx->stats.p;
         k.stats = stats ? d_stats : nullptr;  // no reader, no counting
+        k.tree_scene = k.n_bvh_nodes > 0 ? 1u : 0u;
         if (p->flags & RTHIP_F_NO_BVH) k.n_bvh_nodes = 0;
         // Sample slicing. The GROUPING of the samples (slice_spp) is a function of spp and of the scene alone, so that the image
         // is the same for every band layout / GPU count; whether a launch IS sliced is a scheduling decision (same image).

@@ -114,6 +114,20 @@ def icosphere(subdivisions):
     return tri
 
 
+def uv_sphere(n_lon=250, n_lat=201):
+    """unit sphere as a latitude / longitude mesh, closed: 2 * n_lon * (n_lat - 1) triangles (the default: exactly 100 000 — the
+    "100 k-tri mesh" of SURVEY §8d's C5; an icosphere only offers 20 * 4^k), as an (n, 3, 3) array. A quad of the grid gives two
+    triangles, except in the two polar bands, where one of them has collapsed into the pole and is left out."""
+    lat = np.linspace(0.0, math.pi, n_lat + 1)
+    lon = np.linspace(0.0, 2.0 * math.pi, n_lon + 1)
+    la, lo = np.meshgrid(lat, lon, indexing="ij")
+    pts = np.stack([np.sin(la) * np.cos(lo), np.cos(la), np.sin(la) * np.sin(lo)], -1)  # (n_lat + 1, n_lon + 1, 3)
+    a, b, c, d = pts[:-1, :-1], pts[1:, :-1], pts[1:, 1:], pts[:-1, 1:]
+    rows = slice(0, n_lat - 1)  # (a, b, c) of every band but the southern polar one, (a, c, d) of every band but the northern
+    tri = np.concatenate([np.stack([a[rows], b[rows], c[rows]], -2).reshape(-1, 3, 3), np.stack([a[1:], c[1:], d[1:]], -2).reshape(-1, 3, 3)])
+    return tri
+
+
 def _poisson_positions(n, radius, seed):
     """the placement recipe of game_ggez/src/poisson.rs:10-30 with a fixed seed"""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -175,7 +189,9 @@ def big_scene(n_side=100, seed=7, mesh_subdivisions=None):
     idx[:] = np.where(kind < 0.5, pick, np.where(kind < 0.75, 64 + pick, 128))
     shapes = [Sphere.new(Vector3(0.0, -100.5, -1.0), 100.0, Lambertian.new_from_hex(0x007070)),
               SphereCloud(np.stack([cx, cy, cz], 1), r, mats, idx)]
-    if mesh_subdivisions is not None:
+    if mesh_subdivisions == "uv100k":  # SURVEY §8d as written: one 100 000-triangle mesh
+        shapes.append(Mesh(uv_sphere() * 1.5 + np.array([0.0, 1.5, -6.0]), Metal.new(Vector3(0.9, 0.9, 0.9), 0.0)))
+    elif mesh_subdivisions is not None:
         ico = icosphere(mesh_subdivisions) * 1.5 + np.array([0.0, 1.5, -6.0])
         shapes.append(Mesh(ico, Metal.new(Vector3(0.9, 0.9, 0.9), 0.0)))
     return shapes

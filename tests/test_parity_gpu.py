@@ -215,10 +215,10 @@ def test_bvh_equals_brute_force(oracle_mod, default_camera):
     assert bvh.stats["sphere_tests"] < brute.stats["sphere_tests"] / 4
     assert np.array_equal(bvh.rgba8, brute.rgba8) and np.array_equal(bvh.accum, brute.accum)
     assert bvh.stats["rays"] == brute.stats["rays"]
-    # vs the oracle (brute force, f64). Two bounces: the strict bar. Eight bounces among 400 small curved
-    # reflectors/refractors is chaotic transport: a 1e-7 FP32 rounding difference grows ~10x per bounce on a
-    # r~0.1 sphere, so ~0.2 % of 2-spp pixels legitimately diverge (the SAME formulas evaluated in float on the
-    # CPU — the oracle's f32 mode — diverge from f64 even more). Bar there: >= 99.5 % and no worse than f32-on-CPU.
+    # vs the oracle (brute force, f64), at two and at eight bounces: the strict bar at both. (Rounds 1-2 measured 99.78 % at
+    # depth 8 and called it chaotic transport. It was the sphere discriminant: half_b^2 - (|oc|^2 - r^2) cancels in FP32 for a
+    # small sphere seen from afar, silhouettes moved by a tenth of a pixel; sphere_roots now takes r^2 - |oc - (oc.d) d|^2.
+    # The oracle's f32 mode keeps the reference's formula in float and still shows the loss.)
     shallow = rt.render(flat, 2, max_depth=2)
     ref2, _, _, _ = oracle_mod.render(flat, default_camera, make_params(w, h, 2, 2, 61), precision=64)
     hist2, ok2 = assert_parity(shallow.rgba8, ref2, "BVH scene, depth 2, vs oracle f64")
@@ -227,8 +227,7 @@ def test_bvh_equals_brute_force(oracle_mod, default_camera):
     hist, ok = mismatch_histogram(bvh.rgba8, ref)
     _, ok_f32cpu = mismatch_histogram(ref32, ref)
     print(f"\nbvh scene depth 2: {describe(hist2, ok2)}\nbvh scene depth 8: {describe(hist, ok)} (f32-on-CPU vs f64: {ok_f32cpu * 100:.3f} %)")
-    # ONE named case, measured on MI355X (round 1 and 2): device 99.78 % within 1/255, f32-on-CPU 99.65 %
-    assert ok >= 0.9970 and ok >= ok_f32cpu - 0.0005
+    assert ok >= 0.999, describe(hist, ok)  # measured on MI355X, round 3: 99.96 % (the reference's formula in float on the CPU: 99.64 %)
     assert abs(bvh.stats["rays"] - st["rays"]) <= 5e-3 * st["rays"]
     # picking goes through the same traversal
     rng = np.random.default_rng(1)
@@ -430,16 +429,16 @@ def test_full_size_4k_other_configs_vs_oracle(oracle_mod, default_camera, name):
 
 
 def test_full_size_8k_bvh_properties(oracle_mod, default_camera):
-    """C5 at its full size: 7680x4320, 10 001 spheres + an 81 920-triangle mesh through the BVH, work pool and
+    """C5 at its full size: 7680x4320, 10 001 spheres + a 100 000-triangle mesh through the BVH, work pool and
     leaf-ordered records. Size-independent properties: counter identities, 8-way band split == whole frame (checksum of
     checksums), determinism, and BVH == brute force on a band the linear scan can afford. And every pixel of the 8K frame
-    against the f64 oracle (answering from its own tree, oracle accel == the scan bit for bit): the strict bar at depth 2;
-    at the config's depth 8 the ONE named case of chaotic transport (10 000 small glass / metal spheres, 1 spp: a 1e-7 rounding
-    difference grows ~10x per bounce) — measured on MI355X: device 99.69 % of the 33 M pixels within 1/255, the same formulas in
-    float on the CPU 99.58 %."""
+    against the f64 oracle (answering from its own tree, oracle accel == the scan bit for bit), at depth 2 and at the config's
+    depth 8, both at the strict bar — measured on MI355X in round 3: 99.9991 % and 99.965 % of the 33 M pixels within 1/255 at
+    1 spp (round 2: 99.69 % at depth 8, put down to chaotic transport; it was FP32 cancellation in the sphere discriminant, see
+    sphere_roots in rt_kernels.hip; the reference's own formula evaluated in float on the CPU is still at 99.6 %)."""
     import zlib
     w, h, spp, depth = 7680, 4320, 1, 8
-    flat = flatten(presets.big_scene(100, 7, mesh_subdivisions=6))
+    flat = flatten(presets.big_scene(100, 7, mesh_subdivisions="uv100k"))
     rt = Raytracer.new(w, h, seed=5)
     whole = rt.render(flat, spp, max_depth=depth, flags=abi.F_COUNT_STATS, want_accum=False)
     s = whole.stats
@@ -467,7 +466,7 @@ def test_full_size_8k_bvh_properties(oracle_mod, default_camera):
     hist2, ok2 = assert_parity(shallow.rgba8, ref2, "C5 whole 8K frame, depth 2, vs oracle f64 (accelerated)")
     print(f"\nC5 whole 8K frame vs oracle f64 with its tree ({secs8:.1f} s): depth 2 {describe(hist2, ok2)}\n"
           f"depth 8 {describe(hist8, ok8)} (f32-on-CPU vs f64: {ok8_f32 * 100:.3f} %)")
-    assert ok8 >= 0.9950 and ok8 >= ok8_f32 - 0.0005   # the named case (docstring)
+    assert ok8 >= 0.999, describe(hist8, ok8)   # the strict bar (docstring)
     assert abs(s["rays"] - st8["rays"]) <= 5e-3 * st8["rays"] and abs(shallow.stats["rays"] - st2["rays"]) <= 5e-3 * st2["rays"]
     rt.close()
 
@@ -708,4 +707,35 @@ def test_primary_inline_loop_is_exact(standalone_flat, lights):
         b = rt.render(flat, 4, max_depth=6, flags=fl | abi.F_COUNT_STATS)
         assert np.array_equal(a.accum, b.accum), f"trial {trial} ({n} spheres): {(a.accum != b.accum).any(axis=2).sum()} pixels differ"
         assert a.stats["rays"] == b.stats["rays"] and a.stats["paths"] == b.stats["paths"]
+    rt.close()
+
+
+@pytest.mark.parametrize("name", ["C5", "C4"])
+def test_bvh_configs_at_their_own_settings(oracle_mod, default_camera, name):
+    """VERDICT r02 item 2: the BVH configs against the f64 oracle at THEIR OWN depth and sample count (C5: depth 8, 64 spp at 8K;
+    C4: depth 50, 16 spp at 4K), on a 1920x1080 window of the frame (what the oracle's host threads trace in ~10 s), at the strict
+    bar of north_star: per-channel |delta| <= 1/255 on >= 99.9 % of the pixels. (The 1-spp whole-frame comparisons above are the
+    worst case for chaotic transport — one path per pixel; at the configs' sample counts a diverging path is one of 16 / 64.)"""
+    if name == "C5":
+        scene, (w, h, spp, depth) = presets.big_scene(100, 7, mesh_subdivisions="uv100k"), (7680, 4320, 64, 8)
+        window = (2880, 1080, 1920, 1080)  # x0, y0, width, height: rows 1080..2159 = band 1 of bands of 1080 rows
+    else:
+        scene, (w, h, spp, depth) = presets.mesh_scene(), (3840, 2160, 16, 50)
+        window = (960, 0, 1920, 1080)      # the lower half of the frame: meshes everywhere
+    flat = flatten(scene)
+    rt = Raytracer.new(w, h, seed=1)
+    band = rt.render(flat, spp, max_depth=depth, band_rows=1080, band_first=window[1] // 1080, band_stride=1000, want_accum=False)
+    got = band.rgba8[:, window[0]:window[0] + window[2]]
+    ref, _, st, secs = oracle_mod.render(flat, default_camera, make_params(w, h, spp, depth, 1), precision=64, crop=window, accel=True)
+    hist, ok = mismatch_histogram(got, ref)
+    ref32, _, _, _ = oracle_mod.render(flat, default_camera, make_params(w, h, spp, depth, 1), precision=32, crop=window, accel=True)
+    hist32, ok32 = mismatch_histogram(ref32, ref)
+    _, ok_dev32 = mismatch_histogram(got, ref32)
+    print(f"\n{name} at its own settings ({w}x{h}, depth {depth}, {spp} spp), window {window} vs oracle f64 ({secs:.1f} s, {st['rays']} rays): {describe(hist, ok)}\n"
+          f"   the oracle's own formulas in float on the CPU vs f64: {describe(hist32, ok32)}; device vs that float render: {ok_dev32 * 100:.3f} %")
+    for d in (2, 4):
+        shallow = rt.render(flat, spp, max_depth=d, band_rows=1080, band_first=window[1] // 1080, band_stride=1000, want_accum=False).rgba8[:, window[0]:window[0] + window[2]]
+        refd, _, _, _ = oracle_mod.render(flat, default_camera, make_params(w, h, spp, d, 1), precision=64, crop=window, accel=True)
+        print(f"   depth {d}: {describe(*mismatch_histogram(shallow, refd))}")
+    assert ok >= 0.999
     rt.close()

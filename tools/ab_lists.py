@@ -9,7 +9,7 @@ scale = float(os.environ.get("SPP_SCALE", "1"))
 CONFIGS = {
     "C4": dict(scene=presets.mesh_scene, w=3840, h=2160, spp=16, depth=50),
     "C4L": dict(scene=presets.mesh_scene, lights=presets.standalone_lights, flags=abi.F_POINT_LIGHTS, w=3840, h=2160, spp=16, depth=50),
-    "C5": dict(scene=lambda: presets.big_scene(100, 7, 6), w=7680, h=4320, spp=64, depth=8),
+    "C5": dict(scene=lambda: presets.big_scene(100, 7, "uv100k"), w=7680, h=4320, spp=64, depth=8),
 }
 for name in sys.argv[1:] or ["C4", "C5"]:
     cfg = CONFIGS[name]

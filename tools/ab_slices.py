@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rustracer_amd import Raytracer, abi, flatten, presets
 name = sys.argv[1]
-cfg = {"C4": (presets.mesh_scene, 3840, 2160, 16, 50), "C5": (lambda: presets.big_scene(100, 7, 6), 7680, 4320, 64, 8)}[name]
+cfg = {"C4": (presets.mesh_scene, 3840, 2160, 16, 50), "C5": (lambda: presets.big_scene(100, 7, "uv100k"), 7680, 4320, 64, 8)}[name]
 flat = flatten(cfg[0]())
 rt = Raytracer.new(cfg[1], cfg[2], seed=1)
 rt.upload(flat)

@@ -17,7 +17,7 @@ CONFIGS = {
     "C3": dict(scene=presets.textured_scene, w=3840, h=2160, spp=64, depth=50),
     "C4": dict(scene=presets.mesh_scene, w=3840, h=2160, spp=16, depth=50),
     "C4L": dict(scene=presets.mesh_scene, lights=presets.standalone_lights, flags=abi.F_POINT_LIGHTS, w=3840, h=2160, spp=16, depth=50),
-    "C5": dict(scene=lambda: presets.big_scene(100, 7, 6), w=7680, h=4320, spp=64, depth=8),
+    "C5": dict(scene=lambda: presets.big_scene(100, 7, "uv100k"), w=7680, h=4320, spp=64, depth=8),
 }
 names = sys.argv[1:] or ["C2", "C3", "C4", "C5"]
 lib = abi.lib()

@@ -1,7 +1,7 @@
 import os, sys
 sys.path.insert(0, "/root/repo")
 from rustracer_amd import Raytracer, abi, flatten, presets
-for name, scene, w, h, spp, depth in (("C4", presets.mesh_scene, 3840, 2160, 4, 50), ("C5", lambda: presets.big_scene(100, 7, 6), 7680, 4320, 8, 8)):
+for name, scene, w, h, spp, depth in (("C4", presets.mesh_scene, 3840, 2160, 4, 50), ("C5", lambda: presets.big_scene(100, 7, "uv100k"), 7680, 4320, 8, 8)):
     flat = flatten(scene())
     rt = Raytracer.new(w, h, seed=1)
     s = rt.render(flat, spp, max_depth=depth, want_accum=False, flags=abi.F_COUNT_STATS).stats

@@ -17,7 +17,7 @@ def main():
     if which == "c4":
         flat, (w, h) = flatten(presets.mesh_scene()), (3840, 2160)
     else:
-        flat, (w, h) = flatten(presets.big_scene(100, 7, 6)), (7680, 4320)
+        flat, (w, h) = flatten(presets.big_scene(100, 7, "uv100k")), (7680, 4320)
     cam = Camera.new(-1.8, 1.0, 2.0).as_abi()
     lib = abi.lib()
     fn = lib.rt_prepass_host

@@ -6,7 +6,7 @@ import numpy as np
 from rustracer_amd import Raytracer, abi, flatten, presets
 
 which = sys.argv[1] if len(sys.argv) > 1 else "C4"
-cfg = {"C4": (presets.mesh_scene, 3840, 2160, 16, 50), "C5": (lambda: presets.big_scene(100, 7, 6), 7680, 4320, 64, 8),
+cfg = {"C4": (presets.mesh_scene, 3840, 2160, 16, 50), "C5": (lambda: presets.big_scene(100, 7, "uv100k"), 7680, 4320, 64, 8),
        "C2": (presets.standalone_scene, 3840, 2160, 256, 5)}[which]
 flat = flatten(cfg[0]())
 w, h = cfg[1], cfg[2]
