@@ -171,17 +171,24 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / max(1, args.steps)
 
     # instrumented (untimed) runs of the same seeds: ray counts and the algorithmic-flop counters
-    rays_local, flops_local = 0, 0.0
+    # ... twice: the reference's algorithm (every ray against every shape, ray.rs:47-67: SURVEY §8d's flops), and with
+    # RTHIP_F_COUNT_EXECUTED the tests the production loops really make (primary rays only against the spheres their tile can
+    # reach, none in sky-only tiles): `frac` and `frac_executed`
+    rays_local, flops_local, flops_exec_local = 0, 0.0, 0.0
     lib = abi.lib()
     import ctypes as C
     for k in range(args.steps):
-        st = abi.Stats()
-        p = br.params(args.spp, MAX_DEPTH, abi.F_COUNT_STATS, k)
-        rc = lib.rthip_render_device(rt._ctx, C.byref(p), br.rgba.data_ptr(), None, torch.cuda.current_stream().cuda_stream, C.byref(st))
-        if rc != 0:
-            raise RuntimeError(lib.rthip_last_error(rt._ctx))
-        rays_local += st.rays
-        flops_local += lib.rthip_algorithmic_flops(C.byref(st))
+        for extra in (0, abi.F_COUNT_EXECUTED):
+            st = abi.Stats()
+            p = br.params(args.spp, MAX_DEPTH, abi.F_COUNT_STATS | extra, k)
+            rc = lib.rthip_render_device(rt._ctx, C.byref(p), br.rgba.data_ptr(), None, torch.cuda.current_stream().cuda_stream, C.byref(st))
+            if rc != 0:
+                raise RuntimeError(lib.rthip_last_error(rt._ctx))
+            if extra:
+                flops_exec_local += lib.rthip_algorithmic_flops(C.byref(st))
+            else:
+                rays_local += st.rays
+                flops_local += lib.rthip_algorithmic_flops(C.byref(st))
     t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
     cnt = torch.tensor([float(rays_local), flops_local], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
     if world > 1:
@@ -195,6 +202,7 @@ def main():
         # roofline of the dominant kernel (render_kernel), this rank's launches: flops per launch / avg launch duration
         flops_per_launch = flops_local / max(1, args.steps)
         achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+        achieved_exec = flops_exec_local / max(1, args.steps) / (kernel_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and world == 1:
@@ -232,6 +240,10 @@ def main():
                 "peak": FP32_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
+                "frac_executed": round(achieved_exec / FP32_VALU_PEAK_TFLOPS, 4),
+                "frac_note": "frac: flops of the reference's algorithm (every ray tested against every shape, SURVEY 8d) / kernel time / peak; "
+                             "frac_executed: the same constants over the shape tests the kernel actually executes (RTHIP_F_COUNT_EXECUTED: "
+                             "tests culled per 8x8 tile are not counted)",
                 "traffic": traffic,
                 "kernel_ms_avg": round(kernel_ms, 4),
                 "kernel_ms_slowest_rank": round(kernel_ms_max, 4),
@@ -352,13 +364,16 @@ def config_lines(device, with_cpu=True):
             return st
         counted = run(flags | abi.F_COUNT_STATS)
         flops = lib.rthip_algorithmic_flops(C.byref(counted))
+        counted_exec = run(flags | abi.F_COUNT_STATS | abi.F_COUNT_EXECUTED)
+        flops_exec = lib.rthip_algorithmic_flops(C.byref(counted_exec))
         ms = min(run(flags).kernel_ms for _ in range(frames))
         tflops = flops / (ms * 1e-3) / 1e12
         line = {"config": name, "workload": f"{what}; {w}x{h}, {spp} spp, max_depth {depth}", "spheres": len(flat.spheres), "triangles": len(flat.triangles),
                 "kernel_ms": round(ms, 3), "mrays_per_s": round(counted.rays / ms / 1e3, 1), "rays": counted.rays, "shadow_rays": counted.shadow_rays,
                 "flops_per_ray": round(flops / max(1, counted.rays), 1),
                 "roofline": {"bound": "valu_fp32", "achieved": round(tflops, 3), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(tflops / FP32_VALU_PEAK_TFLOPS, 4)},
+                             "frac": round(tflops / FP32_VALU_PEAK_TFLOPS, 4),
+                             "frac_executed": round(flops_exec / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4)},
                 "scene_setup_s": round(setup_s, 2)}
         if counted.node_tests:
             # bytes the traversal ASKS the memory system for: 16 B per box test (a 32-B node holds two boxes), 48 B per primitive

@@ -21,15 +21,53 @@ if st:
     for row in csv.DictReader(open(st)):
         lines.append(f"| {row['Name'][:70]} | {row['Calls']} | {row['TotalDurationNs']} | {float(row['AverageNs']):.0f} | {row['Percentage']} |")
     lines.append("")
+def code_object_resources(kernel_name):
+    """VGPRs / SGPRs / static LDS / scratch of a kernel from the code object's own metadata (the amdhsa.kernels notes in the
+    compiler's assembly, `make -C rustracer_amd/csrc asm`) — rocprofv3's VGPR_Count / LDS_Block_Size columns are allocation
+    granules of the dispatch packet (they read 36 / 0 for a 72-VGPR kernel with 5 KB of dynamic LDS), not these."""
+    import re, subprocess
+    m = re.search(r"render_kernel<([^>]*)>", kernel_name)
+    if not m:
+        return None
+    mangled = "_Z13render_kernelI" + "".join(("Lb1E" if a.strip() == "true" else "Lb0E" if a.strip() == "false" else f"Li{a.strip()}E") for a in m.group(1).split(",")) + "Ev12KernelParams"
+    asm = os.path.join(root, "rustracer_amd", "csrc", "rt_kernels.s")
+    if not os.path.exists(asm):
+        subprocess.run(["make", "-C", os.path.join(root, "rustracer_amd", "csrc"), "asm"], capture_output=True)
+    if not os.path.exists(asm):
+        return None
+    text = open(asm).read()
+    at = text.find(f".name:           {mangled}\n")
+    if at < 0:
+        return None
+    start = text.rfind("  - .agpr_count", 0, at)
+    block = text[start:text.find("  - .agpr_count", at) if text.find("  - .agpr_count", at) > 0 else len(text)]
+    g = lambda key: int(re.search(rf"\.{key}:\s+(\d+)", block).group(1))
+    return {"vgpr": g("vgpr_count"), "sgpr": g("sgpr_count"), "static_lds": g("group_segment_fixed_size"), "scratch": g("private_segment_fixed_size"), "mangled": mangled}
+
+
 kt = find("trace/**/*kernel_trace.csv")
 render_ns = []
 if kt:
     for row in csv.DictReader(open(kt)):
         if "render_kernel<false" in row["Kernel_Name"]:
             render_ns.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-            meta = (row.get("VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), row.get("Grid_Size"), row.get("Workgroup_Size"))
+            meta = row
     if render_ns:
-        lines.append(f"render_kernel<false, 0, false, true> (the timed kernel) dispatches: {len(render_ns)}, avg {sum(render_ns)/len(render_ns)/1e6:.3f} ms; VGPR/SGPR/LDS/grid/wg = {meta}\n")
+        res = code_object_resources(meta["Kernel_Name"])
+        wg = int(meta.get("Workgroup_Size", meta.get("Workgroup_Size_X", 256)) or 256)
+        # dynamic LDS of the bench launch (rt_launch_render: scan scene of 4 spheres, no texture queue): (256 + 4*4 + 64) * 16 bytes
+        dyn_lds = int(os.environ.get("DYN_LDS", (256 + 16 + 64) * 16))
+        lines.append(f"{meta['Kernel_Name'][:60]} (the timed kernel) dispatches: {len(render_ns)}, avg {sum(render_ns)/len(render_ns)/1e6:.3f} ms; "
+                     f"grid {meta.get('Grid_Size', meta.get('Grid_Size_X'))}, workgroup {wg}")
+        if res:
+            alloc = (res["vgpr"] + 7) // 8 * 8
+            by_vgpr = min(8, 512 // alloc)
+            lds = res["static_lds"] + dyn_lds
+            by_lds = (163840 // lds) * (wg // 64) / 4.0 if lds else 8
+            lines.append(f"resources from the code object ({res['mangled']}): {res['vgpr']} VGPRs (allocated {alloc}), {res['sgpr']} SGPRs, scratch {res['scratch']} B/lane, "
+                         f"LDS {res['static_lds']} static + {dyn_lds} dynamic = {lds} B per workgroup => waves/SIMD: {by_vgpr} by VGPRs, {by_lds:.1f} by LDS => {min(by_vgpr, by_lds):.0f}\n")
+        else:
+            lines.append("(code-object metadata not found: run `make -C rustracer_amd/csrc asm`)\n")
 counters = defaultdict(list)
 for d in ("pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"):
     f = find(f"{d}/**/*counter_collection.csv")
