@@ -26,4 +26,19 @@ for sig, cs in acc.items():
         print(f"   {k:28s} {sum(v)/len(v):.4g}")
     m = lambda k: sum(cs[k])/len(cs[k])
     if "SQ_THREAD_CYCLES_VALU" in cs: print(f"   lane util = {m('SQ_THREAD_CYCLES_VALU')/(m('SQ_ACTIVE_INST_VALU')*64):.3f}")
+    if "render_kernel<false" in sig and "FETCH_SIZE" in cs and "SQ_WAVE_CYCLES" in cs:
+        import json
+        dur = m("_dur_ns") * 1e-9
+        cyc = dur * 2.35e9  # shader cycles of the launch at the measured ~2.35 GHz
+        d = {"sample": "tools/pmc_config.sh, SPP_SCALE=$SPP_SCALE, round 3 kernel", "kernel_ms": round(dur * 1e3, 2),
+             "hbm_fetch_gb_per_s": round(m("FETCH_SIZE") * 1024 * 2 / dur / 1e9, 1), "hbm_fetch_frac_of_peak": round(m("FETCH_SIZE") * 1024 * 2 / dur / 8e12, 4),
+             "l2_hit_rate": round(m("TCC_HIT_sum") / max(1.0, m("TCC_REQ_sum")), 3) if "TCC_REQ_sum" in cs else None,
+             "l1_accesses_per_vmem_read": round(m("TCP_TOTAL_CACHE_ACCESSES_sum") / m("SQ_INSTS_VMEM_RD"), 1) if "TCP_TOTAL_CACHE_ACCESSES_sum" in cs else None,
+             "valu_lane_utilisation": round(m("SQ_THREAD_CYCLES_VALU") / (m("SQ_ACTIVE_INST_VALU") * 64), 3),
+             "valu_issue_slots_used": round(m("SQ_INSTS_VALU") / 1024 / cyc * 2, 3),
+             "wave_cycles_waiting": round(m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES"), 3), "valu_insts_per_wave": round(m("SQ_INSTS_VALU") / m("SQ_WAVES")),
+             "vmem_reads_per_wave": round(m("SQ_INSTS_VMEM_RD") / m("SQ_WAVES")), "waves": int(m("SQ_WAVES")),
+             "resident_waves_per_simd": round(4 * m("SQ_WAVE_CYCLES") / cyc / 1024, 2)}
+        json.dump(d, open("$OUT/derived.json", "w"), indent=1)
+        print("derived:", json.dumps(d))
 PY
