@@ -23,6 +23,9 @@
 #define RT_SLICE_SPP 64u
 #endif
 #define RT_MAX_SLICES 16u
+#ifndef RT_ORDER_MIN_SPP
+#define RT_ORDER_MIN_SPP 16u /* scan scenes: passes of at least this many samples are launched in order of estimated cost */
+#endif
 // scenes with a tree: sample groups of (at least) RT_TREE_SLICE_SPP samples, at most RT_TREE_SLICES of them, always traced by different waves
 #ifndef RT_TREE_SLICE_SPP
 #define RT_TREE_SLICE_SPP 4u
@@ -143,6 +146,7 @@ struct KernelParams {
     const DevLight *lights;
     const DevBvhNodeQ *bvh_nodes;
     const rt_f4 *bvh_recs;
+    const uint32_t *tile_order;        // scan modes: launch order of the pixel groups (expensive first), null = row-major
     const struct RtTilePre *tile_pre;  // MODE_BVH: per wave tile of this launch, the primary-visibility list (rt_prepass.h); null = none
     // outputs
     float *accum;        // context-owned running sum, owned_rows*width*3

@@ -754,7 +754,11 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
         const uint32_t units_x = ((P.width + RT_TILE_W - 1u) / RT_TILE_W) * WPG;        // workgroups per row of tiles
         const uint32_t per = P.n_slices * units_x;                                      // ... times the slices (the fast index)
         uint32_t b = blockIdx.x;
-        if (!P.worklist) {
+        if (WPG == 1u && P.tile_order != nullptr) {
+            // cost-ordered launch (tile_cost_kernel / tile_order_kernel below): expensive pixel groups first, sky last
+            const uint32_t u = b / P.n_slices;
+            b = P.tile_order[u] * P.n_slices + (b - u * P.n_slices);
+        } else if (!P.worklist) {
             const uint32_t row = b / per, rest = b - row * per;
             uint32_t u = rest / P.n_slices;
             const uint32_t sl = rest - u * P.n_slices;
@@ -2048,6 +2052,77 @@ extern "C" hipError_t rt_launch_prepass(const KernelParams *P, void *tile_pre, h
     const uint32_t blocks = tiles_x * tiles_y;
     if (blocks == 0 || P->n_bvh_nodes == 0) return hipSuccess;
     hipLaunchKernelGGL(prepass_kernel, dim3(blocks), dim3(256), 0, stream, *P, (RtTilePre *)tile_pre);
+    return hipGetLastError();
+}
+
+// ---- cost-ordered launches of the scan kernels ---------------------------------------------------------
+// The workgroups of a launch start in index order and the launch ends when the last one does; a pixel group's cost spans 37x
+// (sky only: 44 us per 256 samples; ground + the glass sphere: 1.6 ms), and a launch that holds only a few workgroups per slot
+// (1/8 of a frame per GPU) ended with a tail of whatever expensive groups happened to start late. So: estimate every group's
+// cost from what its primary rays can reach — one cone through the group's 32x8 pixels against every sphere, weighted by what
+// a hit on that material goes on to cost — sort the groups by it (counting sort over 16 classes, one workgroup), and hand the
+// render kernel the order: longest first, so that the launch ends with the cheap ones. A heuristic for the SCHEDULE only: the
+// image does not depend on which workgroup traces which group.
+__global__ __launch_bounds__(256) void tile_cost_kernel(const KernelParams P, uint32_t n_groups, uint32_t *__restrict__ cost) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n_groups) return;
+    const uint32_t tiles_x = (P.width + RT_TILE_W - 1u) / RT_TILE_W;
+    const uint32_t tx = g % tiles_x, ty = g / tiles_x;
+    const uint32_t lrow = ty * RT_TILE_H;
+    uint32_t y = lrow;
+    if (P.band_rows) {
+        const uint32_t k = lrow / P.band_rows;
+        y = (P.band_first + k * P.band_stride) * P.band_rows + (lrow - k * P.band_rows);
+    }
+    // the cone around the group's centre ray that holds its corner rays (and a pixel of slack)
+    const float x0 = float(tx * RT_TILE_W) - 1.0f, x1 = float(tx * RT_TILE_W + RT_TILE_W) + 1.0f, y0 = float(y) - 1.0f, y1 = float(y + RT_TILE_H) + 1.0f;
+    auto dir = [&](float px, float py) { return normalize(mk3(fmaf(P.vhx, py, fmaf(P.hwx, px, P.d00x)), fmaf(P.vhy, py, fmaf(P.hwy, px, P.d00y)), fmaf(P.vhz, py, fmaf(P.hwz, px, P.d00z)))); };
+    const f3 a = dir(0.5f * (x0 + x1), 0.5f * (y0 + y1));
+    const float cos_half = fminf(fminf(dot(a, dir(x0, y0)), dot(a, dir(x1, y0))), fminf(dot(a, dir(x0, y1)), dot(a, dir(x1, y1))));
+    const float sin_half = fast_sqrt(fmaxf(0.0f, 1.0f - cos_half * cos_half));
+    float w = 0.0f;
+    for (uint32_t i = 0; i < P.n_spheres; i++) {
+        const rt_f4 sg = P.sph_geom[i];
+        const f3 q = mk3(sg.x - P.ox, sg.y - P.oy, sg.z - P.oz);
+        const float lq = fast_sqrt(dot(q, q)), rad = fast_sqrt(sg.w);
+        bool reach = lq <= rad;  // the camera is inside
+        if (!reach) {
+            // angle(a, q) <= half angle of the cone + angle under which the sphere is seen
+            const float cq = dot(a, q) * fast_rcp(lq), sq = fast_sqrt(fmaxf(0.0f, 1.0f - cq * cq));
+            const float ss = rad * fast_rcp(lq), cs = fast_sqrt(fmaxf(0.0f, 1.0f - ss * ss));
+            const float cos_sum = cos_half * cs - sin_half * ss, sin_sum = sin_half * cs + cos_half * ss;  // cos / sin of (half + seen)
+            reach = sin_sum < 0.0f || cos_sum <= 0.0f || cq >= cos_sum || (cq > 0.0f && sq <= sin_sum);
+        }
+        if (reach) {
+            const uint32_t kind = __float_as_uint(P.sph_shade[RT_SHADE_RECS * i + 2].x);
+            w += kind == RTHIP_MAT_DIELECTRIC ? 6.0f : (kind == RTHIP_MAT_TEXTURE ? 1.0f : 3.0f);
+        }
+    }
+    if (P.n_planes + P.n_tris != 0u) w += 3.0f;  // (not tested: they are few in a scan scene)
+    cost[g] = w == 0.0f ? 0u : min(15u, 1u + uint32_t(w * 0.75f));
+}
+// order[] = the groups by falling cost class (counting sort; one workgroup; the order inside a class is left to the atomics)
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__restrict__ cost, uint32_t n_groups, uint32_t *__restrict__ order) {
+    __shared__ uint32_t s_count[16], s_cursor[16];
+    if (threadIdx.x < 16u) s_count[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < n_groups; g += 1024u) atomicAdd(&s_count[cost[g]], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t at = 0;
+        for (int c = 15; c >= 0; c--) s_cursor[c] = at, at += s_count[c];
+    }
+    __syncthreads();
+    for (uint32_t g = threadIdx.x; g < n_groups; g += 1024u) order[atomicAdd(&s_cursor[cost[g]], 1u)] = g;
+}
+// order_and_cost: 2 x n_groups dwords; fills the first half with the launch order of P's pixel groups
+extern "C" hipError_t rt_launch_tile_order(const KernelParams *P, uint32_t *order_and_cost, hipStream_t stream) {
+    (void)hipGetLastError();
+    const uint32_t tiles_x = (P->width + RT_TILE_W - 1u) / RT_TILE_W, tiles_y = (P->owned_rows + RT_TILE_H - 1u) / RT_TILE_H;
+    const uint32_t n = tiles_x * tiles_y;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_cost_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, *P, n, order_and_cost + n);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, order_and_cost + n, n, order_and_cost);
     return hipGetLastError();
 }
 

@@ -17,6 +17,7 @@
 #include "rt_device.h"
 #include "rt_prepass.h"
 
+extern "C" hipError_t rt_launch_tile_order(const KernelParams *P, uint32_t *order_and_cost, hipStream_t stream);
 extern "C" hipError_t rt_launch_prepass(const KernelParams *P, void *tile_pre, hipStream_t stream);
 extern "C" hipError_t rt_launch_render(const KernelParams *P, int count_stats, hipStream_t stream);
 extern "C" hipError_t rt_launch_compact(const KernelParams *P, uint32_t *list, uint32_t *count, hipStream_t stream);
@@ -42,7 +43,7 @@ struct rthip_ctx {
     int device = 0;
     std::string err;
     DevBuf sph_geom, sph_shade, pln_geom, tri_geom, materials, texels, tex_info, lights, bvh_nodes, bvh_recs;
-    DevBuf stats, accum, staging_rgba, staging_accum, pick_out, pix_state, worklist, partial, tile_pre;
+    DevBuf stats, accum, staging_rgba, staging_accum, pick_out, pix_state, worklist, partial, tile_pre, tile_order;
     KernelParams base;
     bool have_scene = false, have_camera = false;
     rthip_camera camera;
@@ -286,7 +287,7 @@ void rthip_destroy(rthip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->sph_geom, &ctx->sph_shade, &ctx->pln_geom, &ctx->tri_geom, &ctx->materials, &ctx->texels, &ctx->tex_info, &ctx->lights,
-                      &ctx->bvh_nodes, &ctx->bvh_recs, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out, &ctx->pix_state, &ctx->worklist, &ctx->partial, &ctx->tile_pre})
+                      &ctx->bvh_nodes, &ctx->bvh_recs, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out, &ctx->pix_state, &ctx->worklist, &ctx->partial, &ctx->tile_pre, &ctx->tile_order})
         b->release();
     if (ctx->stats_host) (void)hipHostFree(ctx->stats_host);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -731,6 +732,14 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
                 HIPCHK(ctx, rt_launch_compact(&k, list, count, stream));
                 k.worklist = list, k.worklist_count = count;
             }
+        }
+        // scan scenes: cost-ordered launch (rt_kernels.hip, tile_cost_kernel) — two tiny kernels ahead of the pass; not worth it for
+        // the 1-spp passes of the progressive loop, not needed for scenes with a tree (their waves are single workgroups and sliced)
+        k.tile_order = nullptr;
+        if (!noalloc && !tree_scene && !adaptive && k.n_spheres <= RT_LDS_SPHERES && p->spp >= RT_ORDER_MIN_SPP && groups >= 64 && !getenv("RTHIP_NO_TILE_ORDER")) {
+            if ((st = ensure(ctx, ctx->tile_order, size_t(groups) * 2u * sizeof(uint32_t)))) return st;
+            HIPCHK(ctx, rt_launch_tile_order(&k, (uint32_t *)ctx->tile_order.p, stream));
+            k.tile_order = (const uint32_t *)ctx->tile_order.p;
         }
         if (make_lists) {
             HIPCHK(ctx, rt_launch_prepass(&k, (void *)k.tile_pre, stream));
