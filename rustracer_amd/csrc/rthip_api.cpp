@@ -733,10 +733,14 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
                 k.worklist = list, k.worklist_count = count;
             }
         }
-        // scan scenes: cost-ordered launch (rt_kernels.hip, tile_cost_kernel) — two tiny kernels ahead of the pass; not worth it for
-        // the 1-spp passes of the progressive loop, not needed for scenes with a tree (their waves are single workgroups and sliced)
+        // scan scenes: cost-ordered launch (rt_kernels.hip, tile_cost_kernel) — two tiny kernels ahead of the pass — for the launches
+        // that are sliced for the same reason: too few workgroups per slot to hide their tail (a band of the frame per GPU; measured
+        // on the 1/8-frame launches of C2: 86.5 -> 89.6 % of ideal). A whole 4K frame gains nothing and pays 1 % (the sort, and
+        // neighbouring tiles no longer run side by side). Not for the 1-spp passes of the progressive loop, not for scenes with a
+        // tree (their waves are single workgroups and sliced).
         k.tile_order = nullptr;
-        if (!noalloc && !tree_scene && !adaptive && k.n_spheres <= RT_LDS_SPHERES && p->spp >= RT_ORDER_MIN_SPP && groups >= 64 && !getenv("RTHIP_NO_TILE_ORDER")) {
+        if (!noalloc && !tree_scene && !adaptive && k.n_spheres <= RT_LDS_SPHERES && p->spp >= RT_ORDER_MIN_SPP && groups >= 64 &&
+            groups < RT_SLICE_BELOW_BLOCKS && !getenv("RTHIP_NO_TILE_ORDER")) {
             if ((st = ensure(ctx, ctx->tile_order, size_t(groups) * 2u * sizeof(uint32_t)))) return st;
             HIPCHK(ctx, rt_launch_tile_order(&k, (uint32_t *)ctx->tile_order.p, stream));
             k.tile_order = (const uint32_t *)ctx->tile_order.p;
