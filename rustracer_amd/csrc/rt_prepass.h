@@ -1,16 +1,21 @@
 // rt_prepass.h — primary-visibility lists for MODE_BVH (extension; the scan to equal is raytracer_core/src/shapes/ray.rs:47-67).
 //
+// OPT-IN (RTHIP_F_TILE_LISTS): bit-identical to the plain traversal and measured SLOWER (DESIGN.md section 5, round 3,
+// profiles/r03_bvh_pmc_summary.md); the default kernels carry none of it (render_kernel<.., LISTS = false>).
+//
 // Every primary ray of a pixel — whatever its sample's jitter (lib.rs:282-285) — starts at the camera and runs inside the thin
 // pyramid through the pixel's footprint, and the 64 pixels of a wave's 8x8 tile share one slightly wider pyramid for the whole
-// launch. So the tree is walked ONCE per tile with that pyramid instead of once per primary ray: `prepass_kernel` collects the
-// leaves whose (quantised) boxes the tile's pyramid touches into a list of at most RT_PRE_LEAVES leaves, and gives every pixel
-// a 64-bit mask of the list entries its own pyramid touches. A primary ray then tests exactly the primitives of its pixel's
-// leaves — no node visit, no stack — through the leaf code of bvh_run (rt_kernels.hip); bounce rays traverse as before.
-// A traversal tests a leaf's primitives only after the ray has passed the slab test of that leaf's box; a ray inside the
-// pyramid that passes that test makes the pyramid touch the box, so the candidate set contains every primitive the
-// traversal would test, and the closest hit under "smaller t, then larger index" is the same (bit for bit: same test code).
-// Tiles that touch more than RT_PRE_LEAVES leaves (dense silhouettes, distant meshes) are marked RT_PRE_OVERFLOW and keep
-// traversing.
+// launch. So the tree is walked ONCE per tile with that pyramid: `prepass_kernel` walks it breadth-first (one node per lane),
+// collects up to RT_PRE_COLLECT leaves whose (quantised) boxes the tile's pyramid touches, keeps the RT_PRE_LEAVES nearest
+// in order of (near, reference) — near = a lower bound of the distance from the camera to the leaf's box — and gives every
+// pixel a 64-bit mask of the kept leaves ITS pyramid touches plus a cut distance: the smallest near of a leaf that touches
+// the pixel's pyramid and was not kept. A primary ray tests the leaves of its pixel's mask in list order through the leaf code
+// of the traversal (leaf_test, rt_kernels.hip), stops at the first leaf whose near lies beyond its best hit, and is done if that
+// hit is nearer than the cut; otherwise (and on tiles marked RT_PRE_OVERFLOW) it traverses as before. Bounce rays always traverse.
+// Why the hit is the same: a traversal tests a leaf's primitives only after the ray has passed the slab test of that leaf's
+// box; a ray inside the pyramid that passes that test makes the pyramid touch the box, so the candidates contain every
+// primitive the traversal would test that could be nearer than the cut, and the closest hit under "smaller t, then larger
+// index" is the same (bit for bit: same test code).
 //
 // The geometry below is shared by the device kernel and its host mirror (rt_prepass_host.cpp: the checker of the lists,
 // tests/test_prepass.py), hence plain C++ with RT_HD.
