@@ -647,7 +647,11 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
         float cg = __fsqrt_rn(fminf(fmaxf(acc.y * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
         float cb = __fsqrt_rn(fminf(fmaxf(acc.z * P.inv_nb, 0.0f), 1.0f)) * 255.0f;
         const uint32_t rgb = uint32_t(cr) | (uint32_t(cg) << 8) | (uint32_t(cb) << 16);
+#ifdef RT_TIMELINE
+        if (P.rgba8 && P.n_slices <= 1u) P.rgba8[oi] = rgb | 0xff000000u;  // (debug: the render kernel's time stamps stay, see there)
+#else
         if (P.rgba8) P.rgba8[oi] = rgb | 0xff000000u;
+#endif
         if (P.pix_state) {
             // lib.rs:300-313: compare with last_color, count equal passes, Final after more than 3
             const uint32_t st = P.pix_state[oi];
@@ -754,10 +758,10 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
         const uint32_t units_x = ((P.width + RT_TILE_W - 1u) / RT_TILE_W) * WPG;        // workgroups per row of tiles
         const uint32_t per = P.n_slices * units_x;                                      // ... times the slices (the fast index)
         uint32_t b = blockIdx.x;
-        if (WPG == 1u && P.tile_order != nullptr) {
+        if (P.tile_order != nullptr) {
             // cost-ordered launch (tile_cost_kernel / tile_order_kernel below): expensive pixel groups first, sky last
-            const uint32_t u = b / P.n_slices;
-            b = P.tile_order[u] * P.n_slices + (b - u * P.n_slices);
+            const uint32_t u = b / P.n_slices, g = u / WPG;
+            b = (P.tile_order[g] * WPG + (u - g * WPG)) * P.n_slices + (b - u * P.n_slices);
         } else if (!P.worklist) {
             const uint32_t row = b / per, rest = b - row * per;
             uint32_t u = rest / P.n_slices;
@@ -865,6 +869,7 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
 #ifdef RT_TIMELINE  // debug build (tools/timeline.py): when and where each wave ran, written over the first pixels of its tile
     const unsigned long long tl_start = wall_clock64();
 #endif
+    const unsigned long long t_begin = (!POOL && P.tile_cost_out != nullptr) ? wall_clock64() : 0ull;
     if (amask != 0ull) {
         uint2 *s_pix = s_pix_all + (lwave << 6);
         // MODE_BVH: this wave tile's primary-visibility list (rt_prepass.h), if the launch made them and the tile's fits
@@ -1796,15 +1801,19 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
                 finish_pixel(P, oi, acc, cnt[RT_STAT_PIX_TRACED], cnt[RT_STAT_PIX_FINAL]);
             }
 #ifdef RT_TIMELINE
-            if (P.rgba8 && lane < 6u) {
+            // (a sliced launch: slice k writes over row k of the tile, and finish_pixel() leaves the frame alone in this build)
+            if (P.rgba8 && lane - 8u * (sliced ? slice & 7u : 0u) < 6u) {
                 const unsigned long long tl_end = wall_clock64();
                 const uint32_t v[6] = {uint32_t(tl_start), uint32_t(tl_start >> 32), uint32_t(tl_end), uint32_t(tl_end >> 32),
                                        uint32_t(__builtin_amdgcn_s_getreg(63492)), uint32_t(__builtin_amdgcn_s_getreg(63508))};
-                P.rgba8[oi] = v[lane];
+                P.rgba8[oi] = v[lane & 7u];
             }
 #endif
         }
     }
+
+    // feedback for the next launch's order (tile_order_kernel): how long this wave ran, added to its pixel group's cost
+    if (!POOL && P.tile_cost_out != nullptr && amask != 0ull && lane == 0u) atomicAdd(&P.tile_cost_out[group], uint32_t(wall_clock64() - t_begin));
 
     // per-wave reduction of the counters, one atomic per wave and counter into a shard (skipped when nobody reads them)
     if (!P.stats) return;
@@ -2101,28 +2110,46 @@ __global__ __launch_bounds__(256) void tile_cost_kernel(const KernelParams P, ui
     if (P.n_planes + P.n_tris != 0u) w += 3.0f;  // (not tested: they are few in a scan scene)
     cost[g] = w == 0.0f ? 0u : min(15u, 1u + uint32_t(w * 0.75f));
 }
-// order[] = the groups by falling cost class (counting sort; one workgroup; the order inside a class is left to the atomics)
+// order[] = the groups by falling cost (counting sort over 1024 buckets scaled to the largest cost; one workgroup; the order inside
+// a bucket is left to the atomics). The costs are either the classes of tile_cost_kernel or MEASURED: the wave times a previous
+// launch of the same frame layout added up per group (KernelParams::tile_cost_out).
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__restrict__ cost, uint32_t n_groups, uint32_t *__restrict__ order) {
-    __shared__ uint32_t s_count[16], s_cursor[16];
-    if (threadIdx.x < 16u) s_count[threadIdx.x] = 0u;
+    __shared__ uint32_t s_count[1024], s_scan[1024], s_max;
+    const uint32_t t = threadIdx.x;
+    s_count[t] = 0u;
+    if (t == 0u) s_max = 0u;
     __syncthreads();
-    for (uint32_t g = threadIdx.x; g < n_groups; g += 1024u) atomicAdd(&s_count[cost[g]], 1u);
+    uint32_t m = 0u;
+    for (uint32_t g = t; g < n_groups; g += 1024u) m = max(m, cost[g]);
+    atomicMax(&s_max, m);
     __syncthreads();
-    if (threadIdx.x == 0u) {
-        uint32_t at = 0;
-        for (int c = 15; c >= 0; c--) s_cursor[c] = at, at += s_count[c];
+    const float scale = 1023.0f / float(max(s_max, 1u));
+    auto bucket = [&](uint32_t c) { return 1023u - min(1023u, uint32_t(float(c) * scale)); };  // bucket 0 = the most expensive
+    for (uint32_t g = t; g < n_groups; g += 1024u) atomicAdd(&s_count[bucket(cost[g])], 1u);
+    __syncthreads();
+    // exclusive prefix sum of the bucket counts (Hillis-Steele, 10 steps)
+    uint32_t v = s_count[t];
+    s_scan[t] = v;
+    __syncthreads();
+    for (uint32_t off = 1u; off < 1024u; off <<= 1) {
+        const uint32_t add = t >= off ? s_scan[t - off] : 0u;
+        __syncthreads();
+        s_scan[t] += add;
+        __syncthreads();
     }
+    s_count[t] = s_scan[t] - v;  // the bucket's cursor
     __syncthreads();
-    for (uint32_t g = threadIdx.x; g < n_groups; g += 1024u) order[atomicAdd(&s_cursor[cost[g]], 1u)] = g;
+    for (uint32_t g = t; g < n_groups; g += 1024u) order[atomicAdd(&s_count[bucket(cost[g])], 1u)] = g;
 }
 // order_and_cost: 2 x n_groups dwords; fills the first half with the launch order of P's pixel groups
-extern "C" hipError_t rt_launch_tile_order(const KernelParams *P, uint32_t *order_and_cost, hipStream_t stream) {
+// ... from the cost model (measured == null), or from the costs a previous launch of the same layout measured
+extern "C" hipError_t rt_launch_tile_order(const KernelParams *P, uint32_t *order_and_cost, const uint32_t *measured, hipStream_t stream) {
     (void)hipGetLastError();
     const uint32_t tiles_x = (P->width + RT_TILE_W - 1u) / RT_TILE_W, tiles_y = (P->owned_rows + RT_TILE_H - 1u) / RT_TILE_H;
     const uint32_t n = tiles_x * tiles_y;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_cost_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, *P, n, order_and_cost + n);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, order_and_cost + n, n, order_and_cost);
+    if (!measured) hipLaunchKernelGGL(tile_cost_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, *P, n, order_and_cost + n);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, measured ? measured : order_and_cost + n, n, order_and_cost);
     return hipGetLastError();
 }
 

@@ -17,7 +17,7 @@
 #include "rt_device.h"
 #include "rt_prepass.h"
 
-extern "C" hipError_t rt_launch_tile_order(const KernelParams *P, uint32_t *order_and_cost, hipStream_t stream);
+extern "C" hipError_t rt_launch_tile_order(const KernelParams *P, uint32_t *order_and_cost, const uint32_t *measured, hipStream_t stream);
 extern "C" hipError_t rt_launch_prepass(const KernelParams *P, void *tile_pre, hipStream_t stream);
 extern "C" hipError_t rt_launch_render(const KernelParams *P, int count_stats, hipStream_t stream);
 extern "C" hipError_t rt_launch_compact(const KernelParams *P, uint32_t *list, uint32_t *count, hipStream_t stream);
@@ -43,7 +43,7 @@ struct rthip_ctx {
     int device = 0;
     std::string err;
     DevBuf sph_geom, sph_shade, pln_geom, tri_geom, materials, texels, tex_info, lights, bvh_nodes, bvh_recs;
-    DevBuf stats, accum, staging_rgba, staging_accum, pick_out, pix_state, worklist, partial, tile_pre, tile_order;
+    DevBuf stats, accum, staging_rgba, staging_accum, pick_out, pix_state, worklist, partial, tile_pre, tile_order, tile_cost;
     KernelParams base;
     bool have_scene = false, have_camera = false;
     rthip_camera camera;
@@ -67,6 +67,18 @@ struct rthip_ctx {
     hipEvent_t ev_rendered[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
     DevBuf staging_async[2];
     bool async_busy[2] = {false, false};
+    // Cost-ordered launches (render_pass): what the order in tile_order was made for, and from what. 0 = nothing; 1 = from the cost
+    // model, and the pass that used it MEASURED the groups into tile_cost; 2 = from those measurements (later passes just reuse it).
+    struct OrderKey {
+        uint32_t width, height, rows, band_rows, band_first, band_stride, spp, max_depth, flags;
+        uint64_t frame;
+        bool operator==(const OrderKey &o) const {
+            return width == o.width && height == o.height && rows == o.rows && band_rows == o.band_rows && band_first == o.band_first &&
+                   band_stride == o.band_stride && spp == o.spp && max_depth == o.max_depth && flags == o.flags && frame == o.frame;
+        }
+    } order_key = {};
+    int order_state = 0;
+    uint64_t frame_gen = 1;                    // advances with every scene upload and camera change
     const void *pre_lists = nullptr;           // the primary-visibility lists (rt_prepass.h) made for the running sum's frame, if any:
                                                // RTHIP_F_ACCUMULATE passes of the same frame reuse them (same camera, scene, layout)
 };
@@ -287,7 +299,7 @@ void rthip_destroy(rthip_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->sph_geom, &ctx->sph_shade, &ctx->pln_geom, &ctx->tri_geom, &ctx->materials, &ctx->texels, &ctx->tex_info, &ctx->lights,
-                      &ctx->bvh_nodes, &ctx->bvh_recs, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out, &ctx->pix_state, &ctx->worklist, &ctx->partial, &ctx->tile_pre, &ctx->tile_order})
+                      &ctx->bvh_nodes, &ctx->bvh_recs, &ctx->stats, &ctx->accum, &ctx->staging_rgba, &ctx->staging_accum, &ctx->pick_out, &ctx->pix_state, &ctx->worklist, &ctx->partial, &ctx->tile_pre, &ctx->tile_order, &ctx->tile_cost})
         b->release();
     if (ctx->stats_host) (void)hipHostFree(ctx->stats_host);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -493,6 +505,7 @@ int rthip_upload_scene(rthip_ctx *ctx, const rthip_scene_desc *s) {
         ctx->n_shapes = n_shapes;
         ctx->have_scene = true;
         ctx->nb_samples = 0;  // a new scene invalidates the running sum
+        ctx->frame_gen++;
         ctx->pre_lists = nullptr;
         return RTHIP_OK;
     } catch (const std::bad_alloc &) {
@@ -511,6 +524,7 @@ int rthip_set_camera(rthip_ctx *ctx, const rthip_camera *camera) {
     fill_camera(ctx->base, *camera);
     ctx->have_camera = true;
     ctx->nb_samples = 0;  // standalone/src/main.rs:103-120: a camera command invalidates the pixels
+    ctx->frame_gen++;
     ctx->pre_lists = nullptr;
     return RTHIP_OK;
 }
@@ -733,16 +747,39 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
                 k.worklist = list, k.worklist_count = count;
             }
         }
-        // scan scenes: cost-ordered launch (rt_kernels.hip, tile_cost_kernel) — two tiny kernels ahead of the pass — for the launches
-        // that are sliced for the same reason: too few workgroups per slot to hide their tail (a band of the frame per GPU; measured
-        // on the 1/8-frame launches of C2: 86.5 -> 89.6 % of ideal). A whole 4K frame gains nothing and pays 1 % (the sort, and
-        // neighbouring tiles no longer run side by side). Not for the 1-spp passes of the progressive loop, not for scenes with a
-        // tree (their waves are single workgroups and sliced).
+        // scan scenes: cost-ordered launch (rt_kernels.hip, tile_cost_kernel / tile_order_kernel) for the launches that are sliced
+        // for the same reason: too few workgroups per slot to hide their tail (a band of the frame per GPU). The FIRST pass of a
+        // frame layout (image, bands, scene, camera, samples) takes its order from a cost model — two tiny kernels ahead of the
+        // pass — and measures: every wave adds its run time to its pixel group's cost. The SECOND pass sorts those measurements
+        // (one tiny kernel) and every later pass of the layout just reuses that order: longest groups first, by the clock. (The
+        // model alone: 86.5 -> 89.6 % of ideal on the 1/8-frame launches of C2 — it cannot know which ground tiles' bounce rays
+        // reach the glass sphere, and 150 such workgroups starting late were the last 10 % of the launch, tools/timeline_band.py.)
+        // A schedule only: which workgroup traces which group has no effect on the image. A whole 4K frame gains nothing from the
+        // model and pays 1 % (the sort, and neighbouring tiles no longer run side by side): RTHIP_ORDER_ALL=1 orders it too.
+        // Not for the 1-spp passes of the progressive loop, not for scenes with a tree (their waves are single workgroups, sliced).
         k.tile_order = nullptr;
+        k.tile_cost_out = nullptr;
+        static const bool order_all = getenv("RTHIP_ORDER_ALL") != nullptr, order_none = getenv("RTHIP_NO_TILE_ORDER") != nullptr,
+                          order_model_only = getenv("RTHIP_ORDER_MODEL_ONLY") != nullptr;
         if (!noalloc && !tree_scene && !adaptive && k.n_spheres <= RT_LDS_SPHERES && p->spp >= RT_ORDER_MIN_SPP && groups >= 64 &&
-            groups < RT_SLICE_BELOW_BLOCKS && !getenv("RTHIP_NO_TILE_ORDER")) {
+            (groups < RT_SLICE_BELOW_BLOCKS || order_all) && !order_none) {
+            const rthip_ctx::OrderKey key = {p->width, p->height, rows, p->band_rows, p->band_first, p->band_stride, p->spp, p->max_depth,
+                                             p->flags & (RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_COUNT_EXECUTED), ctx->frame_gen};
             if ((st = ensure(ctx, ctx->tile_order, size_t(groups) * 2u * sizeof(uint32_t)))) return st;
-            HIPCHK(ctx, rt_launch_tile_order(&k, (uint32_t *)ctx->tile_order.p, stream));
+            if ((st = ensure(ctx, ctx->tile_cost, size_t(groups) * sizeof(uint32_t)))) return st;
+            const bool same = ctx->order_state != 0 && ctx->order_key == key;
+            if (same && ctx->order_state == 2) {
+                // the measured order is in place
+            } else if (same && ctx->order_state == 1 && !order_model_only) {
+                HIPCHK(ctx, rt_launch_tile_order(&k, (uint32_t *)ctx->tile_order.p, (const uint32_t *)ctx->tile_cost.p, stream));
+                ctx->order_state = 2;
+            } else {
+                HIPCHK(ctx, hipMemsetAsync(ctx->tile_cost.p, 0, size_t(groups) * sizeof(uint32_t), stream));
+                HIPCHK(ctx, rt_launch_tile_order(&k, (uint32_t *)ctx->tile_order.p, nullptr, stream));
+                k.tile_cost_out = (uint32_t *)ctx->tile_cost.p;
+                ctx->order_key = key;
+                ctx->order_state = 1;
+            }
             k.tile_order = (const uint32_t *)ctx->tile_order.p;
         }
         if (make_lists) {
