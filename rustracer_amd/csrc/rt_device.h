@@ -147,7 +147,7 @@ struct KernelParams {
     const DevBvhNodeQ *bvh_nodes;
     const rt_f4 *bvh_recs;
     const uint32_t *tile_order;        // scan modes: launch order of the pixel groups (expensive first), null = row-major
-    uint32_t *tile_cost_out;           // scan modes: per pixel group, the sum of its waves' run times (100 MHz ticks) is added here; null = not measured
+    uint32_t *tile_cost_out;           // scan modes: per pixel group, the run time of its longest wave (100 MHz ticks; atomic max); null = not measured
     const struct RtTilePre *tile_pre;  // MODE_BVH: per wave tile of this launch, the primary-visibility list (rt_prepass.h); null = none
     // outputs
     float *accum;        // context-owned running sum, owned_rows*width*3

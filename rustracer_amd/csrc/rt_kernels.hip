@@ -1812,8 +1812,10 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
         }
     }
 
-    // feedback for the next launch's order (tile_order_kernel): how long this wave ran, added to its pixel group's cost
-    if (!POOL && P.tile_cost_out != nullptr && amask != 0ull && lane == 0u) atomicAdd(&P.tile_cost_out[group], uint32_t(wall_clock64() - t_begin));
+    // feedback for the next launch's order (tile_order_kernel): how long this wave ran; a pixel group's cost is its LONGEST wave (a
+    // workgroup holds its four wave slots until the slowest wave ends; with the sum as the key, a sky group with one tile on a sphere's
+    // silhouette sorted among the cheap groups and its 260 us wave ended the launch alone, tools/timeline_band.py)
+    if (!POOL && P.tile_cost_out != nullptr && amask != 0ull && lane == 0u) atomicMax(&P.tile_cost_out[group], uint32_t(wall_clock64() - t_begin));
 
     // per-wave reduction of the counters, one atomic per wave and counter into a shard (skipped when nobody reads them)
     if (!P.stats) return;
@@ -2112,7 +2114,7 @@ __global__ __launch_bounds__(256) void tile_cost_kernel(const KernelParams P, ui
 }
 // order[] = the groups by falling cost (counting sort over 1024 buckets scaled to the largest cost; one workgroup; the order inside
 // a bucket is left to the atomics). The costs are either the classes of tile_cost_kernel or MEASURED: the wave times a previous
-// launch of the same frame layout added up per group (KernelParams::tile_cost_out).
+// launch of the same frame layout took per group (its longest wave, KernelParams::tile_cost_out).
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__restrict__ cost, uint32_t n_groups, uint32_t *__restrict__ order) {
     __shared__ uint32_t s_count[1024], s_scan[1024], s_max;
     const uint32_t t = threadIdx.x;

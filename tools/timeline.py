@@ -44,3 +44,11 @@ order = np.argsort(dur.ravel())[::-1][:8]
 for o in order:
     ty, tx = divmod(int(o), dur.shape[1])
     print(f"  long wave: tile ({tx},{ty}) start {s.ravel()[o] / 1e3:.2f} ms dur {dur.ravel()[o] / 1e3:.2f} ms")
+# what an interleaved-band partition of this frame would give each rank (sum of its bands' wave times), straight and zigzag
+band = dur.sum(axis=1)  # one entry per 8-row band
+for world in (2, 4, 8):
+    idx = np.arange(band.size)
+    k, j = idx // world, idx % world
+    for name, owner in (("straight", j), ("zigzag", np.where(k % 2 == 0, j, world - 1 - j))):
+        per = np.array([band[owner == r].sum() for r in range(world)])
+        print(f"  world {world} {name:8s}: max/mean over ranks {per.max() / per.mean():.4f}  per rank (ms of wave time): {' '.join(f'{p / 1e3:.0f}' for p in per)}")
