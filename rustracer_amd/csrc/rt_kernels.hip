@@ -197,7 +197,7 @@ __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
     s.sp = 0;
 }
 #ifndef RT_BVH_LDS_LEVELS
-#define RT_BVH_LDS_LEVELS 8u
+#define RT_BVH_LDS_LEVELS 6u
 #endif
 #ifndef RT_BVH_TOP_NODES
 #define RT_BVH_TOP_NODES 0  /* > 0: stage that many nodes of the top of the tree in LDS — measured slower at every size */
@@ -682,11 +682,12 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 //    idle lanes come from divergent shading branches, not from unequal pixels — hence not used there.)
 //
 // Dynamic LDS layout (bytes): [MODE_LDS: RT_LDS_SPHERES x 16 geometry | 3 x n_spheres x 16 shading]
-// [MODE_BVH: bvh_levels x 256 x 4 traversal stack | 4 waves x 64 x 8 per-pixel {RNG key, x | y << 16}
-// | 4 waves x 3 x 64*ring_rows x 4 radiance slots | 4 waves x 16 x 4 finished paths per ring row]; rt_launch_render computes the size.
+// [MODE_BVH, per wave (a workgroup is one wave there): bvh_levels x 64 x 4 traversal stack | 64 x 4 RNG keys of the tile's pixels + 8 x 4
+// image rows of the tile's rows (work-list passes: 64 x 4 x | y << 16) | 3 x 64*ring_rows x 4 radiance slots | 16 x 4 finished paths
+// per ring row | 16 x 8 "ended at a texture" masks per ring row]; rt_launch_render computes the size.
 // MODE_BVH needs resident waves to cover its node fetches (every visit is a dependent, divergent 32-byte fetch): its speed follows
 // the number of waves (measured on C4/C5: 4 -> 5 -> 6 -> 7 waves per SIMD = 1.00 / 1.11 / 1.18 / 1.21), so the kernel is held to
-// 72 VGPRs (20 dwords of spills, outside the traversal loop) and its LDS to 22 KB per workgroup (see rt_launch_render).
+// 72 VGPRs (spills outside the traversal loop) and its LDS to 4 allocation blocks of 1280 B per wave (see rt_launch_render).
 #ifdef RT_ARM_COUNTS  // debug build (with RT_CLASS_CYCLES): how often a divergent arm runs (x 64) and for how many lanes
 #define RT_ARM_COUNT(slot_execs, slot_lanes)                                                                                    \
     {                                                                                                                           \
@@ -790,8 +791,11 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
     rt_f4 *s_geom_mem = (rt_f4 *)(s_dyn + (QUEUE ? WGW * RT_QUEUE_WAVE_DWORDS * 4u : 0u));
     rt_f4 *s_shade_mem = s_geom_mem + (MODE == MODE_LDS ? (QUEUE ? n_padded : RT_LDS_SPHERES) : 0u);
     uint32_t *s_stack = (uint32_t *)(s_shade_mem + (MODE == MODE_LDS ? RT_SHADE_RECS * P.n_spheres : 0u));
-    uint2 *s_pix_all = (uint2 *)(s_stack + (MODE == MODE_BVH ? P.bvh_levels * WGT : 0u));  // per pixel {RNG key, x | y << 16}
-    float *s_L_all = (float *)(s_pix_all + WGT);
+    // MODE_BVH, per wave: the RNG key of each of its pixels, then the image row of each of its tile's 8 rows (72 dwords) — or, for the
+    // scattered pixels of a work-list pass, x | y << 16 of each pixel (128 dwords)
+    const uint32_t pix_dwords = P.worklist ? 128u : 72u;
+    uint32_t *s_pix_all = s_stack + (MODE == MODE_BVH ? P.bvh_levels * WGT : 0u);
+    float *s_L_all = (float *)(s_pix_all + (MODE == MODE_BVH ? pix_dwords * WGW : 0u));
     // MODE_BVH: the staged top of the tree sits behind the ring and its row counters (rt_launch_render sizes it)
     lds_u4 *s_top = (lds_u4 *)((uint32_t *)(s_L_all + WGW * 3u * (P.ring_rows << 6)) + 16u * WGW);
     const uint32_t n_top = (RT_BVH_TOP_NODES > 0 && MODE == MODE_BVH) ? P.bvh_top_nodes : 0u;
@@ -871,7 +875,7 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
 #endif
     const unsigned long long t_begin = (!POOL && P.tile_cost_out != nullptr) ? wall_clock64() : 0ull;
     if (amask != 0ull) {
-        uint2 *s_pix = s_pix_all + (lwave << 6);
+        uint32_t *s_pix = s_pix_all + lwave * pix_dwords;
         // MODE_BVH: this wave tile's primary-visibility list (rt_prepass.h), if the launch made them and the tile's fits
         const RtTilePre *pre_tile = nullptr;
         const RtTileEnt *pre_list = nullptr;
@@ -894,9 +898,14 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
             pp.y = fmaf(P.vy, pv, fmaf(P.hy, pu, P.d00y));
             pp.z = fmaf(P.vz, pv, fmaf(P.hz, pu, P.d00z));
             pp.w = __uint_as_float(rt_pixel_key(rt_seed_key(P.seed), y * P.width + x));
-            if (POOL) s_pix[lane] = make_uint2(__float_as_uint(pp.w), x | (y << 16));
+            if (POOL) {
+                s_pix[lane] = __float_as_uint(pp.w);
+                if (P.worklist) s_pix[64u + lane] = x | (y << 16);
+                else if ((lane & 7u) == 0u) s_pix[64u + (lane >> 3)] = y;
+            }
             pp_own = pp;
         }
+        const uint32_t x_tile0 = uint32_t(__builtin_amdgcn_readfirstlane(int(x - (lane & 7u))));  // first column of the wave's tile
         const f3 cam_o = mk3(P.ox, P.oy, P.oz);
         f3 cam_v = cam_o;  // ... in vector registers: operand of the moves in next_ray
         asm volatile("" : "+v"(cam_v.x), "+v"(cam_v.y), "+v"(cam_v.z));
@@ -1233,10 +1242,18 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
             uint32_t k = key + RT_RNG_GOLDEN;  // RNG slot 1 + bounce
             if (POOL) {
                 if (fresh) {
-                    // the pixel's key and coordinates (8 B of LDS per pixel); its base direction is recomputed: 10 instructions
-                    // per path are nothing next to a traversal, and 2 KB of LDS per workgroup are an extra workgroup per CU
-                    const uint2 px = s_pix[pixel];
-                    const float pu = float(px.y & 0xffffu) * P.inv_wm1, pv = float(px.y >> 16) * P.inv_hm1;
+                    // the pixel's key (4 B of LDS per pixel) and coordinates (its row's y from the tile's 8-entry table, x from the tile's
+                    // first column); its base direction is recomputed: 10 instructions per path are nothing next to a traversal, and
+                    // LDS is what limits the resident waves (rt_launch_render)
+                    const uint2 px = make_uint2(s_pix[pixel], 0u);
+                    uint32_t fx = x_tile0 + (pixel & 7u), fy;
+                    if (P.worklist) {
+                        const uint32_t xy = s_pix[64u + pixel];
+                        fx = xy & 0xffffu, fy = xy >> 16;
+                    } else {
+                        fy = s_pix[64u + (pixel >> 3)];
+                    }
+                    const float pu = float(fx) * P.inv_wm1, pv = float(fy) * P.inv_hm1;
                     pp.x = fmaf(P.vx, pv, fmaf(P.hx, pu, P.d00x));
                     pp.y = fmaf(P.vy, pv, fmaf(P.hy, pu, P.d00y));
                     pp.z = fmaf(P.vz, pv, fmaf(P.hz, pu, P.d00z));
@@ -2232,9 +2249,13 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
         if (const char *e = getenv("RTHIP_BVH_TOP")) top = RT_BVH_TOP_NODES > 0 ? uint32_t(atoi(e)) : 0u;
         if (top > P.bvh_top_nodes) top = P.bvh_top_nodes;
         P.bvh_top_nodes = top;
-        // per wave: stack levels x 64 lanes, 64 x {RNG key, x | y << 16}, 3 colour planes x ring rows x 64 radiance slots, 16 row counters
+        // per wave: stack levels x 64 lanes, the pixel table (72 dwords; 128 in a work-list pass), 3 colour planes x ring rows x 64 radiance slots,
+        // 16 row counters, 16 row masks
         const uint32_t waves = RT_WG_THREADS(MODE_BVH) / 64u;
-        lds = waves * (P.bvh_levels * 256u + 512u + 3u * 64u * 4u * P.ring_rows + 16u * 4u + 16u * 8u) + top * 32u;
+        // (gfx950 hands out LDS in blocks of 1280 B, 128 per CU: 6 levels + the pixel keys + a ring of 4 rows = 5088 B = 4 blocks per one-wave
+        // workgroup, so 28 waves fit a CU = the 7 per SIMD that 72 VGPRs allow; at 5 blocks (8 levels and a wider pixel table, round 2) 25 fit.
+        // Measured with RTHIP_STACK_LDS, tools/stack_lds_sweep.py: C4 56.1 / 56.6 / 57.4 ms at 8 / 7 / 6 levels of 5 blocks, 54.5 at 4 blocks.)
+        lds = waves * (P.bvh_levels * 256u + (P.worklist ? 128u : 72u) * 4u + 3u * 64u * 4u * P.ring_rows + 16u * 4u + 16u * 8u) + top * 32u;
     } else {
         P.ring_rows = 1;  // lane = pixel: no radiance slots
         P.bvh_levels = 0;
