@@ -761,8 +761,11 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
         uint32_t b = blockIdx.x;
         if (P.tile_order != nullptr) {
             // cost-ordered launch (tile_cost_kernel / tile_order_kernel below): expensive pixel groups first, sky last
-            const uint32_t u = b / P.n_slices, g = u / WPG;
-            b = (P.tile_order[g] * WPG + (u - g * WPG)) * P.n_slices + (b - u * P.n_slices);
+            const uint32_t u = b / P.n_slices;
+            uint32_t g = u / WPG, w = u - g * WPG;
+            // (one-wave workgroups, as below: the four tiles of a pixel group 8 positions apart = on one XCD, where the launch allows it)
+            if (WPG == 4u && P.n_slices == 1u && u < (gridDim.x & ~31u)) g = ((u >> 5) << 3) | (u & 7u), w = (u >> 3) & 3u;
+            b = (P.tile_order[g] * WPG + w) * P.n_slices + (b - u * P.n_slices);
         } else if (!P.worklist) {
             const uint32_t row = b / per, rest = b - row * per;
             uint32_t u = rest / P.n_slices;
@@ -873,7 +876,7 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
 #ifdef RT_TIMELINE  // debug build (tools/timeline.py): when and where each wave ran, written over the first pixels of its tile
     const unsigned long long tl_start = wall_clock64();
 #endif
-    const unsigned long long t_begin = (!POOL && P.tile_cost_out != nullptr) ? wall_clock64() : 0ull;
+    const unsigned long long t_begin = P.tile_cost_out != nullptr ? wall_clock64() : 0ull;
     if (amask != 0ull) {
         uint32_t *s_pix = s_pix_all + lwave * pix_dwords;
         // MODE_BVH: this wave tile's primary-visibility list (rt_prepass.h), if the launch made them and the tile's fits
@@ -1832,7 +1835,7 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
     // feedback for the next launch's order (tile_order_kernel): how long this wave ran; a pixel group's cost is its LONGEST wave (a
     // workgroup holds its four wave slots until the slowest wave ends; with the sum as the key, a sky group with one tile on a sphere's
     // silhouette sorted among the cheap groups and its 260 us wave ended the launch alone, tools/timeline_band.py)
-    if (!POOL && P.tile_cost_out != nullptr && amask != 0ull && lane == 0u) atomicMax(&P.tile_cost_out[group], uint32_t(wall_clock64() - t_begin));
+    if (P.tile_cost_out != nullptr && amask != 0ull && lane == 0u) atomicMax(&P.tile_cost_out[group], uint32_t(wall_clock64() - t_begin));
 
     // per-wave reduction of the counters, one atomic per wave and counter into a shard (skipped when nobody reads them)
     if (!P.stats) return;

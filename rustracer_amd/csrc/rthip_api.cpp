@@ -686,6 +686,21 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         const uint64_t groups = (p->flags & RTHIP_F_ADAPTIVE) && accumulate ? (uint64_t(rows) * p->width + 255u) / 256u
                                                                              : uint64_t((p->width + RT_TILE_W - 1u) / RT_TILE_W) * ((rows + RT_TILE_H - 1u) / RT_TILE_H);
         if (tree_scene ? groups * 4u >= RT_TREE_SLICE_BELOW_WAVES : groups >= RT_SLICE_BELOW_BLOCKS) k.n_slices = 1;
+        // Launch order by measured cost (further down): which launches take part, and what identifies a frame layout.
+        //  * scan scenes: the launches that are sliced for the same reason — too few workgroups per slot to hide their tail;
+        //  * scenes with a tree: the launches that would be sliced; once their groups have been measured (the first pass of the
+        //    layout: row order, sliced) they start longest-first and need NO slices — the heavy tiles start at t = 0 and the launch
+        //    ends with sky tiles, without the ramp-down every slice costs: C4 54.4 (4 slices) -> 49.9 ms. Launches that are not
+        //    sliced anyway gain nothing from the order (C5: 397.9 vs 397.3 ms) and keep the row order (neighbouring tiles side by side).
+        static const bool order_all = getenv("RTHIP_ORDER_ALL") != nullptr, order_none = getenv("RTHIP_NO_TILE_ORDER") != nullptr,
+                          order_model_only = getenv("RTHIP_ORDER_MODEL_ONLY") != nullptr, order_tree = getenv("RTHIP_NO_TREE_ORDER") == nullptr;
+        const bool scan_ordered = !tree_scene && k.n_spheres <= RT_LDS_SPHERES && p->spp >= RT_ORDER_MIN_SPP && (groups < RT_SLICE_BELOW_BLOCKS || order_all);
+        const bool tree_ordered = tree_scene && k.n_bvh_nodes > 0 && order_tree && p->spp >= RT_TREE_SLICE_SPP && groups * 4u < RT_TREE_SLICE_BELOW_WAVES;
+        const bool ordered = !noalloc && !adaptive && groups >= 64 && (scan_ordered || tree_ordered) && !order_none;
+        const rthip_ctx::OrderKey order_key = {p->width, p->height, rows, p->band_rows, p->band_first, p->band_stride, p->spp, p->max_depth,
+                                               p->flags & (RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_COUNT_EXECUTED), ctx->frame_gen};
+        const bool order_measured = ordered && ctx->order_state != 0 && ctx->order_key == order_key && !order_model_only;  // this pass starts its groups by measured cost
+        if (tree_ordered && order_measured) k.n_slices = 1;
         if (k.n_slices > 1) {
             const size_t need = size_t(k.n_slices) * rows * p->width * 3 * sizeof(float);
             if (noalloc) {
@@ -747,40 +762,34 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
                 k.worklist = list, k.worklist_count = count;
             }
         }
-        // scan scenes: cost-ordered launch (rt_kernels.hip, tile_cost_kernel / tile_order_kernel) for the launches that are sliced
-        // for the same reason: too few workgroups per slot to hide their tail (a band of the frame per GPU). The FIRST pass of a
-        // frame layout (image, bands, scene, camera, samples) takes its order from a cost model — two tiny kernels ahead of the
-        // pass — and measures: every wave adds its run time to its pixel group's cost. The SECOND pass sorts those measurements
-        // (one tiny kernel) and every later pass of the layout just reuses that order: longest groups first, by the clock. (The
-        // model alone: 86.5 -> 89.6 % of ideal on the 1/8-frame launches of C2 — it cannot know which ground tiles' bounce rays
-        // reach the glass sphere, and 150 such workgroups starting late were the last 10 % of the launch, tools/timeline_band.py.)
-        // A schedule only: which workgroup traces which group has no effect on the image. A whole 4K frame gains nothing from the
-        // model and pays 1 % (the sort, and neighbouring tiles no longer run side by side): RTHIP_ORDER_ALL=1 orders it too.
-        // Not for the 1-spp passes of the progressive loop, not for scenes with a tree (their waves are single workgroups, sliced).
+        // Cost-ordered launch (rt_kernels.hip, tile_cost_kernel / tile_order_kernel). The FIRST pass of a frame layout (image, bands,
+        // scene, camera, samples) takes its order from a cost model (scan scenes: two tiny kernels ahead of the pass) or runs in row
+        // order (tree scenes), and MEASURES: every wave reports its run time to its pixel group. The SECOND pass sorts those
+        // measurements (one tiny kernel) and every later pass of the layout just reuses that order: the groups with the longest
+        // waves first, by the clock. (The model alone: 86.5 -> 89.6 % of ideal on the 1/8-frame launches of C2 — it cannot know
+        // which ground tiles' bounce rays reach the glass sphere, and 150 such workgroups starting late were the last 10 % of the
+        // launch, tools/timeline_band.py; measured: 92 %.) A schedule only: which workgroup traces which group has no effect on the
+        // image. A whole 4K frame of a scan scene gains nothing from either order and pays 1 % for the model's (the sort, and
+        // neighbouring tiles no longer run side by side): RTHIP_ORDER_ALL=1 orders it too. Not for the 1-spp passes of the
+        // progressive loop, not for work-list passes.
         k.tile_order = nullptr;
         k.tile_cost_out = nullptr;
-        static const bool order_all = getenv("RTHIP_ORDER_ALL") != nullptr, order_none = getenv("RTHIP_NO_TILE_ORDER") != nullptr,
-                          order_model_only = getenv("RTHIP_ORDER_MODEL_ONLY") != nullptr;
-        if (!noalloc && !tree_scene && !adaptive && k.n_spheres <= RT_LDS_SPHERES && p->spp >= RT_ORDER_MIN_SPP && groups >= 64 &&
-            (groups < RT_SLICE_BELOW_BLOCKS || order_all) && !order_none) {
-            const rthip_ctx::OrderKey key = {p->width, p->height, rows, p->band_rows, p->band_first, p->band_stride, p->spp, p->max_depth,
-                                             p->flags & (RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_COUNT_EXECUTED), ctx->frame_gen};
+        if (ordered) {
             if ((st = ensure(ctx, ctx->tile_order, size_t(groups) * 2u * sizeof(uint32_t)))) return st;
             if ((st = ensure(ctx, ctx->tile_cost, size_t(groups) * sizeof(uint32_t)))) return st;
-            const bool same = ctx->order_state != 0 && ctx->order_key == key;
-            if (same && ctx->order_state == 2) {
+            if (order_measured && ctx->order_state == 2) {
                 // the measured order is in place
-            } else if (same && ctx->order_state == 1 && !order_model_only) {
+            } else if (order_measured) {
                 HIPCHK(ctx, rt_launch_tile_order(&k, (uint32_t *)ctx->tile_order.p, (const uint32_t *)ctx->tile_cost.p, stream));
                 ctx->order_state = 2;
             } else {
                 HIPCHK(ctx, hipMemsetAsync(ctx->tile_cost.p, 0, size_t(groups) * sizeof(uint32_t), stream));
-                HIPCHK(ctx, rt_launch_tile_order(&k, (uint32_t *)ctx->tile_order.p, nullptr, stream));
+                if (!tree_scene) HIPCHK(ctx, rt_launch_tile_order(&k, (uint32_t *)ctx->tile_order.p, nullptr, stream));
                 k.tile_cost_out = (uint32_t *)ctx->tile_cost.p;
-                ctx->order_key = key;
+                ctx->order_key = order_key;
                 ctx->order_state = 1;
             }
-            k.tile_order = (const uint32_t *)ctx->tile_order.p;
+            if (!tree_scene || ctx->order_state == 2) k.tile_order = (const uint32_t *)ctx->tile_order.p;
         }
         if (make_lists) {
             HIPCHK(ctx, rt_launch_prepass(&k, (void *)k.tile_pre, stream));

@@ -26,14 +26,18 @@ def _pass(lib, ctx, entry, p):
     return rgba.cpu().numpy(), acc.cpu().numpy().view(np.uint32), st.as_dict()
 
 
-@pytest.mark.parametrize("case", ["sliced", "unsliced", "band"])
+@pytest.mark.parametrize("case", ["sliced", "unsliced", "band", "tree", "tree-band"])
 def test_every_state_of_the_launch_order_gives_the_row_order_bytes(case):
     lib = abi.lib()
-    flat = flatten(presets.standalone_scene())
+    tree = case.startswith("tree")
+    # tree scenes (401 spheres + 320 triangles): pass 1 runs sliced in row order and measures, pass 2.. run UNSLICED, longest waves first
+    flat = flatten(presets.big_scene(n_side=20, seed=3, mesh_subdivisions=2)) if tree else flatten(presets.standalone_scene())
     w, h = 960, 544  # 30 x 68 = 2040 pixel groups: ordered (>= 64, < 20 000)
     p = {"sliced": make_params(w, h, 130, 5, 77, abi.F_COUNT_STATS),                                   # 3 slices
          "unsliced": make_params(w, h, 24, 50, 78, 0),                                                 # one slice, no counters
-         "band": make_params(w, h, 70, 5, 79, 0, band_rows=8, band_first=1, band_stride=2)}[case]      # a rank's bands
+         "band": make_params(w, h, 70, 5, 79, 0, band_rows=8, band_first=1, band_stride=2),            # a rank's bands
+         "tree": make_params(w, h, 16, 8, 80, 0),
+         "tree-band": make_params(w, h, 13, 50, 81, abi.F_COUNT_STATS, band_rows=16, band_first=2, band_stride=3)}[case]
     ordered, plain = Raytracer.new(w, h, seed=p.seed), Raytracer.new(w, h, seed=p.seed)
     for rt in (ordered, plain):
         rt.upload(flat)
