@@ -331,9 +331,9 @@ def config_lines(device, with_cpu=True):
     lib = abi.lib()
     configs = [
         ("C2+light", "standalone scene + one point light (5,5,5): reflections depth 5 + shadow rays (BASELINE config 2 as worded)",
-         presets.standalone_scene, presets.standalone_lights, abi.F_POINT_LIGHTS, 3840, 2160, 256, 5, 2),
+         presets.standalone_scene, presets.standalone_lights, abi.F_POINT_LIGHTS, 3840, 2160, 256, 5, 3),
         ("C3", "textured scene: 9 textured spheres + textured quad + ground", presets.textured_scene, None, 0, 3840, 2160, 64, 50, 3),
-        ("C4", "1,003,520-triangle mesh scene, linear BVH", presets.mesh_scene, None, 0, 3840, 2160, 16, 50, 3),
+        ("C4", "1,003,520-triangle mesh scene, linear BVH", presets.mesh_scene, None, 0, 3840, 2160, 16, 50, 4),
         ("C5", "10,001 spheres + one 100,000-triangle mesh, BVH, depth 8", lambda: presets.big_scene(100, 7, "uv100k"), None, 0, 7680, 4320, 64, 8, 2),
     ]
     pmc = {}

@@ -740,6 +740,9 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
                              5 KB of LDS and runs its own cone tests; measured on C2: 12.17 -> 12.32 ms */
 #endif
 #define RT_WG_THREADS(MODE) (((MODE) == MODE_BVH ? RT_POOL_WAVE_WG : RT_SCAN_WAVE_WG) ? 64 : 256)
+#ifndef RT_PRIMARY_INLINE_DEN
+#define RT_PRIMARY_INLINE_DEN 2u /* the primary-inline loop serves the waves whose primary rays can reach at most 1/DEN of the spheres */
+#endif
 #ifndef RT_ROW_ROTATE
 #define RT_ROW_ROTATE 3u
 #endif
@@ -1376,7 +1379,7 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
                 tile_empty = SPH_SCENE && __ballot(active && can_hit) == 0ull;
                 pmask = pm;
                 // worth it where paths are short: the wave's primary rays see few of the spheres (the ground, mostly)
-                primary_inline = RT_PRIMARY_INLINE && !tile_empty && P.n_spheres <= 64u && 2u * uint32_t(__popcll(pm)) <= P.n_spheres;
+                primary_inline = RT_PRIMARY_INLINE && !tile_empty && P.n_spheres <= 64u && RT_PRIMARY_INLINE_DEN * uint32_t(__popcll(pm)) <= P.n_spheres;
             }
 #ifdef RT_CLASS_CYCLES  // debug build: wall-clock ticks (100 MHz) and waves per tile class, in the hit / test counters
             const unsigned long long t_class0 = wall_clock64();

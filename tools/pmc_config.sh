@@ -14,8 +14,13 @@ python3 - <<PY
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(f)):
-        if "render_kernel" in row["Kernel_Name"]:
+    rows = [r for r in csv.DictReader(open(f)) if "render_kernel" in r["Kernel_Name"]]
+    # the LAST dispatch of each kernel: the steady state of the launch order (pass 1 of a layout measures, pass 2 sorts, rthip_api.cpp)
+    last = {}
+    for r in rows:
+        last[r["Kernel_Name"]] = max(last.get(r["Kernel_Name"], 0), int(r["Dispatch_Id"]))
+    for row in rows:
+        if int(row["Dispatch_Id"]) == last[row["Kernel_Name"]]:
             acc[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
             acc[row["Kernel_Name"][:60]]["_dur_ns"].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
             acc[row["Kernel_Name"][:60]]["_vgpr"] = [float(row["VGPR_Count"])]
@@ -30,7 +35,7 @@ for sig, cs in acc.items():
         import json
         dur = m("_dur_ns") * 1e-9
         cyc = dur * 2.35e9  # shader cycles of the launch at the measured ~2.35 GHz
-        d = {"sample": "tools/pmc_config.sh, SPP_SCALE=$SPP_SCALE, round 3 kernel", "kernel_ms": round(dur * 1e3, 2),
+        d = {"sample": "tools/pmc_config.sh, SPP_SCALE=$SPP_SCALE, round 3 kernel, last dispatch (steady launch order)", "kernel_ms": round(dur * 1e3, 2),
              "hbm_fetch_gb_per_s": round(m("FETCH_SIZE") * 1024 * 2 / dur / 1e9, 1), "hbm_fetch_frac_of_peak": round(m("FETCH_SIZE") * 1024 * 2 / dur / 8e12, 4),
              "l2_hit_rate": round(m("TCC_HIT_sum") / max(1.0, m("TCC_REQ_sum")), 3) if "TCC_REQ_sum" in cs else None,
              "l1_accesses_per_vmem_read": round(m("TCP_TOTAL_CACHE_ACCESSES_sum") / m("SQ_INSTS_VMEM_RD"), 1) if "TCP_TOTAL_CACHE_ACCESSES_sum" in cs else None,

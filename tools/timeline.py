@@ -12,7 +12,8 @@ flat = flatten(cfg[0]())
 w, h = cfg[1], cfg[2]
 rt = Raytracer.new(w, h, seed=1)
 fl = 0 if os.environ.get("PLAIN", "1") == "1" else abi.F_TILE_LISTS
-rt.render(flat, cfg[3], max_depth=cfg[4], want_accum=False, flags=fl)
+for _ in range(int(os.environ.get("WARM", "2"))):  # (pass 1 measures the groups, pass 2 sorts them: the third runs in the final order)
+    rt.render(flat, cfg[3], max_depth=cfg[4], want_accum=False, flags=fl)
 r = rt.render(flat, cfg[3], max_depth=cfg[4], want_accum=False, flags=fl)
 img = r.rgba8.view(np.uint32).reshape(h, w)
 t = img[0::8]  # first row of every tile
@@ -32,6 +33,8 @@ for i in range(40):
     print(f"  t={mid / 1e3:6.2f} ms resident waves {n:5d} " + "#" * (n // 120))
 for k in range(8):
     m = xcc == k
+    if not m.any():
+        continue
     print(f"  XCD {k}: waves {int(m.sum())} last end {e[m].max() / 1e3:.2f} ms, wave time {dur[m].sum() / 1e6:.2f} s")
 cu = (hw >> 8) & 0xF
 se = (hw >> 13) & 0x7
