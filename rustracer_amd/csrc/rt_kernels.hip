@@ -681,7 +681,7 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 //    independent of which lane traced what. (Measured: the pool costs the scan modes 9 % — their
 //    idle lanes come from divergent shading branches, not from unequal pixels — hence not used there.)
 //
-// Dynamic LDS layout (bytes): [MODE_LDS: RT_LDS_SPHERES x 16 geometry | 3 x n_spheres x 16 shading]
+// Dynamic LDS layout (bytes): [MODE_LDS: padded n_spheres x 16 geometry | 4 x n_spheres x 16 shading | 64 x 16 camera terms]
 // [MODE_BVH, per wave (a workgroup is one wave there): bvh_levels x 64 x 4 traversal stack | 64 x 4 RNG keys of the tile's pixels + 8 x 4
 // image rows of the tile's rows (work-list passes: 64 x 4 x | y << 16) | 3 x 64*ring_rows x 4 radiance slots | 16 x 4 finished paths
 // per ring row | 16 x 8 "ended at a texture" masks per ring row]; rt_launch_render computes the size.
@@ -736,20 +736,24 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
                              workgroups a third of the resident-wave time was waves waiting for their slowest sibling */
 #endif
 #ifndef RT_SCAN_WAVE_WG
-#define RT_SCAN_WAVE_WG 0 /* the scan modes keep 256-thread workgroups: with one wave per workgroup every wave stages the scene in its own
-                             5 KB of LDS and runs its own cone tests; measured on C2: 12.17 -> 12.32 ms */
+#define RT_SCAN_WAVE_WG 1 /* MODE_LDS, scenes of few spheres: one-wave workgroups too (the instantiation VAR = true; rt_launch_render picks it when a
+                             wave's own copy of the staged scene fits 4 LDS allocation blocks, i.e. 28 waves still fit a CU). A wave's slot is free
+                             when IT ends: C2 12.18 -> 12.03 ms, its 1/8-frame launches 1.644 -> 1.609 ms. (Round 3 first measured this 1 % SLOWER:
+                             the staged geometry then took RT_LDS_SPHERES entries whatever the scene, 5 blocks per wave, 25 waves per CU.) */
 #endif
-#define RT_WG_THREADS(MODE) (((MODE) == MODE_BVH ? RT_POOL_WAVE_WG : RT_SCAN_WAVE_WG) ? 64 : 256)
+// VAR: the fifth template parameter of render_kernel — MODE_BVH: the primary-visibility list code (LISTS); MODE_LDS: one-wave workgroups
+#define RT_WG_THREADS(MODE, VAR) (((MODE) == MODE_BVH ? RT_POOL_WAVE_WG : ((MODE) == MODE_LDS && (VAR))) ? 64 : 256)
 #ifndef RT_PRIMARY_INLINE_DEN
 #define RT_PRIMARY_INLINE_DEN 2u /* the primary-inline loop serves the waves whose primary rays can reach at most 1/DEN of the spheres */
 #endif
 #ifndef RT_ROW_ROTATE
 #define RT_ROW_ROTATE 3u
 #endif
-template <bool STATS, int MODE, bool LIGHTS, bool SPH_SCENE, bool LISTS = false>
-__global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_BVH_LIGHT_WAVES : RT_SCAN_LIGHT_WAVES) : (MODE == MODE_BVH ? RT_BVH_WAVES : (SPH_SCENE ? RT_SCAN_SPH_WAVES : RT_SCAN_WAVES)))) void render_kernel(const KernelParams P) {
+template <bool STATS, int MODE, bool LIGHTS, bool SPH_SCENE, bool VAR = false>
+__global__ __launch_bounds__(RT_WG_THREADS(MODE, VAR), STATS ? 4 : (LIGHTS ? (MODE == MODE_BVH ? RT_BVH_LIGHT_WAVES : RT_SCAN_LIGHT_WAVES) : (MODE == MODE_BVH ? RT_BVH_WAVES : (SPH_SCENE ? RT_SCAN_SPH_WAVES : RT_SCAN_WAVES)))) void render_kernel(const KernelParams P) {
     constexpr bool POOL = MODE == MODE_BVH;
-    constexpr uint32_t WGT = RT_WG_THREADS(MODE);  // threads of this workgroup; a pixel group (32x8 pixels, or 256 work-list entries) is 256 / WGT workgroups
+    constexpr bool LISTS = MODE == MODE_BVH && VAR;
+    constexpr uint32_t WGT = RT_WG_THREADS(MODE, VAR);  // threads of this workgroup; a pixel group (32x8 pixels, or 256 work-list entries) is 256 / WGT workgroups
     constexpr uint32_t WGW = WGT / 64u;           // ... its waves
     // Position of this thread / workgroup in the launch's sequence of 256-pixel groups. Workgroups go to the 8 XCDs round-robin
     // by their index, and a row of a 4K / 8K frame is a multiple of 8 groups: with the plain row-major order every XCD would
@@ -792,10 +796,9 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE), STATS ? 4 : (LIGHTS ? (MODE ==
     constexpr bool DEFCLASS = !LIGHTS;
     constexpr bool QUEUE = RT_TEX_QUEUE != 0 && !STATS && MODE == MODE_LDS && !LIGHTS;
     const uint32_t n_padded = (P.n_spheres + RT_SCAN_UNROLL - 1u) & ~(RT_SCAN_UNROLL - 1u);
-    // QUEUE: [per wave: the queue, RT_QUEUE_WAVE_DWORDS] [geometry, padded sphere count] [shading records] [primary table]
-    // else   [geometry, RT_LDS_SPHERES] [shading records] [primary table]  (the geometry base is a constant either way)
+    // [QUEUE: per wave, the queue, RT_QUEUE_WAVE_DWORDS] [geometry, padded sphere count] [shading records] [primary table]
     rt_f4 *s_geom_mem = (rt_f4 *)(s_dyn + (QUEUE ? WGW * RT_QUEUE_WAVE_DWORDS * 4u : 0u));
-    rt_f4 *s_shade_mem = s_geom_mem + (MODE == MODE_LDS ? (QUEUE ? n_padded : RT_LDS_SPHERES) : 0u);
+    rt_f4 *s_shade_mem = s_geom_mem + (MODE == MODE_LDS ? n_padded : 0u);
     uint32_t *s_stack = (uint32_t *)(s_shade_mem + (MODE == MODE_LDS ? RT_SHADE_RECS * P.n_spheres : 0u));
     // MODE_BVH, per wave: the RNG key of each of its pixels, then the image row of each of its tile's 8 rows (72 dwords) — or, for the
     // scattered pixels of a work-list pass, x | y << 16 of each pixel (128 dwords)
@@ -2196,24 +2199,29 @@ __global__ void pick_kernel(const KernelParams P, float u, float v, long long *o
 
 // ---- launch wrappers (called from rthip_api.cpp) -----------------------------------------
 template <bool STATS, int MODE, bool SPH_SCENE>
-static void launch_variant(const KernelParams &P, bool lights, uint32_t blocks, uint32_t lds, hipStream_t stream) {
-    constexpr uint32_t wgt = RT_WG_THREADS(MODE);  // MODE_BVH: one workgroup per wave tile, 256 / wgt workgroups per pixel group
-    const dim3 grid(blocks * P.n_slices * (256u / wgt)), block(wgt);
-    if (MODE == MODE_BVH && P.tile_pre != nullptr) {  // RTHIP_F_TILE_LISTS: the instantiation with the primary-visibility list code
-        if (lights) hipLaunchKernelGGL((render_kernel<STATS, MODE, true, SPH_SCENE, MODE == MODE_BVH>), grid, block, lds, stream, P);
-        else hipLaunchKernelGGL((render_kernel<STATS, MODE, false, SPH_SCENE, MODE == MODE_BVH>), grid, block, lds, stream, P);
+static void launch_variant(const KernelParams &P, bool lights, uint32_t blocks, uint32_t lds, bool var, hipStream_t stream) {
+    // var — MODE_BVH: RTHIP_F_TILE_LISTS, the instantiation with the primary-visibility list code; MODE_LDS: one-wave workgroups
+    // (MODE_BVH always has them: 256 / wgt workgroups per pixel group)
+    constexpr bool can_var = MODE == MODE_BVH || (MODE == MODE_LDS && !STATS && RT_SCAN_WAVE_WG);
+    if (can_var && var) {
+        constexpr uint32_t wgt = RT_WG_THREADS(MODE, true);
+        const dim3 grid(blocks * P.n_slices * (256u / wgt)), block(wgt);
+        if (lights) hipLaunchKernelGGL((render_kernel<STATS, MODE, true, SPH_SCENE, can_var>), grid, block, lds, stream, P);
+        else hipLaunchKernelGGL((render_kernel<STATS, MODE, false, SPH_SCENE, can_var>), grid, block, lds, stream, P);
     } else {
+        constexpr uint32_t wgt = RT_WG_THREADS(MODE, false);
+        const dim3 grid(blocks * P.n_slices * (256u / wgt)), block(wgt);
         if (lights) hipLaunchKernelGGL((render_kernel<STATS, MODE, true, SPH_SCENE>), grid, block, lds, stream, P);
         else hipLaunchKernelGGL((render_kernel<STATS, MODE, false, SPH_SCENE>), grid, block, lds, stream, P);
     }
 }
 
 template <bool STATS>
-static void launch_mode(const KernelParams &P, int mode, bool lights, uint32_t blocks, uint32_t lds, hipStream_t stream) {
-    if (mode == MODE_BVH) launch_variant<STATS, MODE_BVH, false>(P, lights, blocks, lds, stream);
-    else if (mode == MODE_LDS && P.n_planes == 0 && P.n_tris == 0) launch_variant<STATS, MODE_LDS, true>(P, lights, blocks, lds, stream);
-    else if (mode == MODE_LDS) launch_variant<STATS, MODE_LDS, false>(P, lights, blocks, lds, stream);
-    else launch_variant<STATS, MODE_GLOBAL, false>(P, lights, blocks, lds, stream);
+static void launch_mode(const KernelParams &P, int mode, bool lights, uint32_t blocks, uint32_t lds, bool var, hipStream_t stream) {
+    if (mode == MODE_BVH) launch_variant<STATS, MODE_BVH, false>(P, lights, blocks, lds, var, stream);
+    else if (mode == MODE_LDS && P.n_planes == 0 && P.n_tris == 0) launch_variant<STATS, MODE_LDS, true>(P, lights, blocks, lds, var, stream);
+    else if (mode == MODE_LDS) launch_variant<STATS, MODE_LDS, false>(P, lights, blocks, lds, var, stream);
+    else launch_variant<STATS, MODE_GLOBAL, false>(P, lights, blocks, lds, false, stream);
 }
 
 // MODE_BVH: sample rows in the per-wave radiance ring (768 B of LDS per row and wave; measured on C4: 2 rows 77 ms, 4 rows 61 ms,
@@ -2241,6 +2249,7 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
     const bool lights = (P.flags & RTHIP_F_POINT_LIGHTS) && P.n_lights > 0;
     const int mode = P.n_bvh_nodes > 0 ? MODE_BVH : ((P.n_spheres <= RT_LDS_SPHERES && !P.tree_scene) ? MODE_LDS : MODE_GLOBAL);
     uint32_t lds = 0;
+    bool var = mode == MODE_BVH && P.tile_pre != nullptr;  // the fifth template parameter of render_kernel (launch_variant)
     if (mode == MODE_BVH) {
         if (P.bvh_levels == 0 || P.bvh_levels > RT_BVH_MAX_DEPTH) return hipErrorInvalidValue;
         P.ring_rows = default_ring_rows();  // rows of the radiance ring: a power of two <= 16
@@ -2257,7 +2266,7 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
         P.bvh_top_nodes = top;
         // per wave: stack levels x 64 lanes, the pixel table (72 dwords; 128 in a work-list pass), 3 colour planes x ring rows x 64 radiance slots,
         // 16 row counters, 16 row masks
-        const uint32_t waves = RT_WG_THREADS(MODE_BVH) / 64u;
+        const uint32_t waves = RT_WG_THREADS(MODE_BVH, false) / 64u;
         // (gfx950 hands out LDS in blocks of 1280 B, 128 per CU: 6 levels + the pixel keys + a ring of 4 rows = 5088 B = 4 blocks per one-wave
         // workgroup, so 28 waves fit a CU = the 7 per SIMD that 72 VGPRs allow; at 5 blocks (8 levels and a wider pixel table, round 2) 25 fit.
         // Measured with RTHIP_STACK_LDS, tools/stack_lds_sweep.py: C4 56.1 / 56.6 / 57.4 ms at 8 / 7 / 6 levels of 5 blocks, 54.5 at 4 blocks.)
@@ -2269,16 +2278,18 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
         // (the variant with the deferred texture queue: the queues first, then geometry sized by the scene — see render_kernel)
         const bool queue = RT_TEX_QUEUE != 0 && !count_stats && !lights;
         const uint32_t n_padded = (P.n_spheres + RT_SCAN_UNROLL - 1u) & ~(RT_SCAN_UNROLL - 1u);
-        const uint32_t wg_waves = RT_WG_THREADS(MODE_LDS) / 64u;
         if (mode != MODE_LDS) lds = 16u;
-        else if (queue) lds = wg_waves * RT_QUEUE_WAVE_DWORDS * 4u + (n_padded + RT_SHADE_RECS * P.n_spheres + RT_PRIMARY_SPHERES) * 16u;
-        else lds = (RT_LDS_SPHERES + RT_SHADE_RECS * P.n_spheres + RT_PRIMARY_SPHERES) * 16u;
+        else if (queue) lds = 4u * RT_QUEUE_WAVE_DWORDS * 4u + (n_padded + RT_SHADE_RECS * P.n_spheres + RT_PRIMARY_SPHERES) * 16u;
+        else lds = (n_padded + RT_SHADE_RECS * P.n_spheres + RT_PRIMARY_SPHERES) * 16u;
+        // one-wave workgroups (every wave stages the scene for itself) while 28 of them fit a CU's 128 LDS allocation blocks of 1280 B:
+        // scenes of up to 51 spheres (RT_SCAN_WAVE_WG)
+        var = mode == MODE_LDS && !queue && !count_stats && (lds + 1279u) / 1280u <= 4u;
     }
     if (lds > 65536u) return hipErrorInvalidValue;
     if (P.n_slices == 0 || P.slice_spp == 0 || (P.n_slices > 1 && (uint64_t(P.n_slices) * P.slice_spp < P.spp || !P.partial))) return hipErrorInvalidValue;
     // (whether the launch is sliced — n_slices > 1 — is the caller's decision, render_pass in rthip_api.cpp; same image either way)
-    if (count_stats) launch_mode<true>(P, mode, lights, blocks, lds, stream);
-    else launch_mode<false>(P, mode, lights, blocks, lds, stream);
+    if (count_stats) launch_mode<true>(P, mode, lights, blocks, lds, var, stream);
+    else launch_mode<false>(P, mode, lights, blocks, lds, var, stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || P.n_slices == 1) return e;
     const uint32_t rblocks = uint32_t((uint64_t(P.owned_rows) * P.width + 255u) / 256u);
