@@ -55,15 +55,15 @@ if kt:
     if render_ns:
         res = code_object_resources(meta["Kernel_Name"])
         wg = int(meta.get("Workgroup_Size", meta.get("Workgroup_Size_X", 256)) or 256)
-        # dynamic LDS of the bench launch (rt_launch_render: scan scene of 4 spheres, no texture queue): (256 + 4*4 + 64) * 16 bytes
-        dyn_lds = int(os.environ.get("DYN_LDS", (256 + 16 + 64) * 16))
+        # dynamic LDS of the bench launch (rt_launch_render: scan scene of 4 spheres, no texture queue): (4 + 4*4 + 64) * 16 bytes
+        dyn_lds = int(os.environ.get("DYN_LDS", (4 + 16 + 64) * 16))
         lines.append(f"{meta['Kernel_Name'][:60]} (the timed kernel) dispatches: {len(render_ns)}, avg {sum(render_ns)/len(render_ns)/1e6:.3f} ms; "
                      f"grid {meta.get('Grid_Size', meta.get('Grid_Size_X'))}, workgroup {wg}")
         if res:
             alloc = (res["vgpr"] + 7) // 8 * 8
             by_vgpr = min(8, 512 // alloc)
             lds = res["static_lds"] + dyn_lds
-            by_lds = (163840 // lds) * (wg // 64) / 4.0 if lds else 8
+            by_lds = (128 // -(-lds // 1280)) * (wg // 64) / 4.0 if lds else 8  # gfx950 allocates LDS in blocks of 1280 B, 128 per CU
             lines.append(f"resources from the code object ({res['mangled']}): {res['vgpr']} VGPRs (allocated {alloc}), {res['sgpr']} SGPRs, scratch {res['scratch']} B/lane, "
                          f"LDS {res['static_lds']} static + {dyn_lds} dynamic = {lds} B per workgroup => waves/SIMD: {by_vgpr} by VGPRs, {by_lds:.1f} by LDS => {min(by_vgpr, by_lds):.0f}\n")
         else:
