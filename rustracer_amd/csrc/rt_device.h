@@ -147,6 +147,10 @@ struct KernelParams {
     const DevBvhNodeQ *bvh_nodes;
     const rt_f4 *bvh_recs;
     const uint32_t *tile_order;        // scan modes: launch order of the pixel groups (expensive first), null = row-major
+    // Mixed launches (tile_order != null and mixed != 0): of the ordered pixel groups, the first head_groups are traced slice by slice
+    // (their waves are long against the launch), those up to whole_end in one piece, the rest slice by slice again (the end of the launch
+    // is made of short pieces); n_slices / partial serve the sliced ones. mixed == 0: every group the same way (n_slices).
+    uint32_t mixed, head_groups, whole_end, n_groups;
     uint32_t *tile_cost_out;           // scan modes: per pixel group, the run time of its longest wave (100 MHz ticks; atomic max); null = not measured
     const struct RtTilePre *tile_pre;  // MODE_BVH: per wave tile of this launch, the primary-visibility list (rt_prepass.h); null = none
     // outputs

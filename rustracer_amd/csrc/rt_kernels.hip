@@ -761,12 +761,31 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE, VAR), STATS ? 4 : (LIGHTS ? (MO
     // ones. So each row of tiles starts RT_ROW_ROTATE columns further to the right than the one below it (wrapping around):
     // an XCD's tiles lie on diagonals. Which workgroup traces a tile has no effect on the image.
     uint32_t tid, bid;
+    uint32_t ns = P.n_slices;  // slices of THIS workgroup's pixel group (a mixed launch traces some groups whole and some in slices)
     {
         constexpr uint32_t WPG = 256u / WGT;                                             // workgroups per pixel group (1, or 4 one-wave workgroups)
         const uint32_t units_x = ((P.width + RT_TILE_W - 1u) / RT_TILE_W) * WPG;        // workgroups per row of tiles
         const uint32_t per = P.n_slices * units_x;                                      // ... times the slices (the fast index)
         uint32_t b = blockIdx.x;
-        if (P.tile_order != nullptr) {
+        if (P.tile_order != nullptr && P.mixed) {
+            // cost-ordered mixed launch: [head_groups sliced] [whole groups] [the rest sliced], expensive first (rthip_api.cpp render_pass)
+            const uint32_t head_units = P.head_groups * WPG * P.n_slices, whole_units = (P.whole_end - P.head_groups) * WPG;
+            uint32_t g, w, sl = 0u;
+            if (b >= head_units && b - head_units < whole_units) {
+                const uint32_t u = b - head_units;
+                g = u / WPG, w = u - g * WPG;
+                if (WPG == 4u && u < (whole_units & ~31u)) g = ((u >> 5) << 3) | (u & 7u), w = (u >> 3) & 3u;  // (a group's tiles on one XCD, as below)
+                g += P.head_groups;
+                ns = 1u;
+            } else {
+                const uint32_t v = b < head_units ? b : b - head_units - whole_units;
+                const uint32_t u = v / P.n_slices;
+                sl = v - u * P.n_slices;
+                g = u / WPG, w = u - g * WPG;
+                g += b < head_units ? 0u : P.whole_end;
+            }
+            b = (P.tile_order[g] * WPG + w) * ns + sl;
+        } else if (P.tile_order != nullptr) {
             // cost-ordered launch (tile_cost_kernel / tile_order_kernel below): expensive pixel groups first, sky last
             const uint32_t u = b / P.n_slices;
             uint32_t g = u / WPG, w = u - g * WPG;
@@ -784,10 +803,10 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE, VAR), STATS ? 4 : (LIGHTS ? (MO
             if (RT_ROW_ROTATE != 0u) u = (u + RT_ROW_ROTATE * WPG * row) % units_x;  // (whole pixel groups)
             b = row * per + u * P.n_slices + sl;
         }
-        // b = (index of the wave tile / pixel group in row-major order) * n_slices + slice
-        const uint32_t wt = b / P.n_slices, sl = b - wt * P.n_slices;
+        // b = (index of the wave tile / pixel group in row-major order) * ns + slice
+        const uint32_t wt = b / ns, sl = b - wt * ns;
         tid = WPG == 1u ? threadIdx.x : ((wt & 3u) << 6) | threadIdx.x;
-        bid = WPG == 1u ? b : (wt >> 2) * P.n_slices + sl;
+        bid = WPG == 1u ? b : (wt >> 2) * ns + sl;
     }
     extern __shared__ __align__(16) unsigned char s_dyn[];
     // DEFCLASS: the radiance of paths that end at a texture after at least one bounce is summed apart from the other samples of
@@ -837,11 +856,11 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE, VAR), STATS ? 4 : (LIGHTS ? (MO
     // Whether a launch is sliced is a scheduling decision (rt_launch_render: only when the grid is too small to fill the
     // GPU otherwise); the IMAGE does not depend on it, because the unsliced kernel adds the samples in the same groups:
     // sum = (...((g0 + g1) + g2)...), g_k = the sequential sum of samples [k*slice_spp, (k+1)*slice_spp).
-    const bool sliced = P.n_slices > 1;
+    const bool sliced = ns > 1;
     // the slice is the FAST index of the grid: the slices of a tile are scheduled together, so that the launch ends with the
     // last (cheap, sky) tiles of the image rather than with the expensive tiles of its last slice
-    const uint32_t slice = sliced ? bid % P.n_slices : 0u;
-    const uint32_t group = sliced ? bid / P.n_slices : bid;  // tile (or block of the work-list)
+    const uint32_t slice = sliced ? bid % ns : 0u;
+    const uint32_t group = sliced ? bid / ns : bid;  // tile (or block of the work-list)
     const uint32_t s_first = slice * P.slice_spp;
     const uint32_t n_spp = sliced ? min(P.slice_spp, P.spp - s_first) : P.spp;
     uint32_t x, lrow;
@@ -1828,10 +1847,11 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE, VAR), STATS ? 4 : (LIGHTS ? (MO
             }
 #ifdef RT_TIMELINE
             // (a sliced launch: slice k writes over row k of the tile, and finish_pixel() leaves the frame alone in this build)
-            if (P.rgba8 && lane - 8u * (sliced ? slice & 7u : 0u) < 6u) {
+            // (pixels 6 and 7 of the row: a marker | the slices of this workgroup's group, and | its slice — the rows of a mixed launch's whole groups keep older data)
+            if (P.rgba8 && lane - 8u * (sliced ? slice & 7u : 0u) < 8u) {
                 const unsigned long long tl_end = wall_clock64();
-                const uint32_t v[6] = {uint32_t(tl_start), uint32_t(tl_start >> 32), uint32_t(tl_end), uint32_t(tl_end >> 32),
-                                       uint32_t(__builtin_amdgcn_s_getreg(63492)), uint32_t(__builtin_amdgcn_s_getreg(63508))};
+                const uint32_t v[8] = {uint32_t(tl_start), uint32_t(tl_start >> 32), uint32_t(tl_end), uint32_t(tl_end >> 32),
+                                       uint32_t(__builtin_amdgcn_s_getreg(63492)), uint32_t(__builtin_amdgcn_s_getreg(63508)), 0xC0FFEE00u | ns, 0xC0FFEE00u | slice};
                 P.rgba8[oi] = v[lane & 7u];
             }
 #endif
@@ -1868,6 +1888,14 @@ __global__ __launch_bounds__(256) void resolve_kernel(const KernelParams P) {
     const size_t npx = size_t(P.owned_rows) * P.width;
     bool in = gi < npx;
     size_t oi = gi;
+    if (P.mixed) {
+        // a mixed launch: workgroup i finishes the i-th SLICED pixel group of the launch order (32 x 8 pixels)
+        const uint32_t g = P.tile_order[blockIdx.x < P.head_groups ? blockIdx.x : P.whole_end + (blockIdx.x - P.head_groups)];
+        const uint32_t tiles_x = (P.width + RT_TILE_W - 1u) / RT_TILE_W;
+        const uint32_t x = (g % tiles_x) * RT_TILE_W + (threadIdx.x & (RT_TILE_W - 1u)), lrow = (g / tiles_x) * RT_TILE_H + threadIdx.x / RT_TILE_W;
+        in = x < P.width && lrow < P.owned_rows;
+        oi = size_t(lrow) * P.width + x;
+    }
     if (P.worklist) {
         in = gi < *P.worklist_count;
         oi = in ? P.worklist[gi] : 0u;
@@ -2138,14 +2166,30 @@ __global__ __launch_bounds__(256) void tile_cost_kernel(const KernelParams P, ui
     if (P.n_planes + P.n_tris != 0u) w += 3.0f;  // (not tested: they are few in a scan scene)
     cost[g] = w == 0.0f ? 0u : min(15u, 1u + uint32_t(w * 0.75f));
 }
+#ifndef RT_TAIL_FACTOR
+#define RT_TAIL_FACTOR 1.0f
+#endif
 // order[] = the groups by falling cost (counting sort over 1024 buckets scaled to the largest cost; one workgroup; the order inside
 // a bucket is left to the atomics). The costs are either the classes of tile_cost_kernel or MEASURED: the wave times a previous
 // launch of the same frame layout took per group (its longest wave, KernelParams::tile_cost_out).
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__restrict__ cost, uint32_t n_groups, uint32_t *__restrict__ order) {
-    __shared__ uint32_t s_count[1024], s_scan[1024], s_max;
+// split (optional, two dwords: head_groups, whole_end) — the MIXED launch of measured costs: order = [head: traced slice by slice]
+// [traced in one piece] [tail: slice by slice]. With c the time of a wave that traces a group's tile in one piece and
+// T = sum(work of a group) / slots the launch time the costs predict,
+//   * head = the groups with c > T / 4: one of their waves in one piece would be a quarter of the launch or more;
+//   * tail: a launch ends with a drain — the last pieces to start run for their c while the slots around them empty — that costs about
+//     half of that c on every slot. So the cheapest groups that are worth it (c above 2 % of T: not the sky) are MOVED to the very end of
+//     the order and traced in slices, as many of them as keep every slot busy for the time of one whole piece of their level
+//     (work >= RT_TAIL_FACTOR * slots * c): the launch ends with pieces of c / slices.
+//   * the groups that cost next to nothing (below 2 % of T: sky) are SPREAD evenly over the part traced in one piece instead of closing
+//     the launch: their waves live for 10-40 us, the GPU starts ~30 waves per us, and 40 000 of them in a row were the last 0.7 ms of the
+//     12-ms frame with a third of the slots filled (tools/timeline_mixed.py). tmp: n_groups dwords of scratch for that.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__restrict__ cost, uint32_t n_groups, uint32_t *__restrict__ order,
+                                                          uint32_t *__restrict__ split, uint32_t *__restrict__ tmp, float slots, float work_mult, float whole_mult) {
+    __shared__ uint32_t s_count[1024], s_scan[1024], s_max, s_start[1024], s_cnt[1024], s_take[1024], s_moved_before[1024], s_moved, s_head, s_trivial;
     const uint32_t t = threadIdx.x;
     s_count[t] = 0u;
-    if (t == 0u) s_max = 0u;
+    s_take[t] = 0u, s_moved_before[t] = 0u;
+    if (t == 0u) s_max = 0u, s_moved = 0u, s_head = 0u, s_trivial = 0u;
     __syncthreads();
     uint32_t m = 0u;
     for (uint32_t g = t; g < n_groups; g += 1024u) m = max(m, cost[g]);
@@ -2165,19 +2209,78 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
         s_scan[t] += add;
         __syncthreads();
     }
-    s_count[t] = s_scan[t] - v;  // the bucket's cursor
+    s_start[t] = s_scan[t] - v;  // where the bucket starts in the sorted order
+    s_cnt[t] = v;
+    s_count[t] = 0u;             // ... and from here on: the groups of the bucket placed so far
     __syncthreads();
-    for (uint32_t g = t; g < n_groups; g += 1024u) order[atomicAdd(&s_count[bucket(cost[g])], 1u)] = g;
+    if (split != nullptr && t == 0u) {
+        // (bucket b holds costs around (1023 - b + 0.5) x the bucket width: everything below is in that unit.
+        // work_mult: waves per group x slices of the measuring pass — a group's work is work_mult x its cost; whole_mult: those slices —
+        // a wave that traces the group's tile in one piece runs for whole_mult x the cost)
+        float total = 0.0f;
+        for (int b = 0; b < 1024; b++) total += float(s_cnt[b]) * (float(1023 - b) + 0.5f);
+        const float t_launch = total * work_mult / slots;
+        uint32_t head = 0;
+        int head_buckets = 0;
+        for (; head_buckets < 1024 && (float(1023 - head_buckets) + 0.5f) * whole_mult > 0.25f * t_launch; head_buckets++) head += s_cnt[head_buckets];
+        float fine = 0.0f;  // the work of the groups moved so far
+        uint32_t trivial = 0;
+        for (int b = 1023; b >= head_buckets; b--) {
+            const uint32_t have = s_cnt[b];
+            const float c = float(1023 - b) + 0.5f, whole = c * whole_mult, need = RT_TAIL_FACTOR * slots * whole, per = work_mult * c;
+            if (whole <= 0.02f * t_launch) trivial += have;
+            if (have == 0u || whole <= 0.02f * t_launch) continue;
+            if (fine >= need) break;
+            const uint32_t take = min(have, uint32_t((need - fine) / per) + 1u);
+            s_take[b] = take;
+            fine += float(take) * per;
+            if (take < have) break;
+        }
+        uint32_t moved = 0;
+        for (int b = 0; b < 1024; b++) s_moved_before[b] = moved, moved += s_take[b];
+        s_moved = moved;
+        s_head = head, s_trivial = trivial;
+        split[0] = head;
+        split[1] = n_groups - moved;
+    }
+    __syncthreads();
+    const uint32_t tail_at = n_groups - s_moved;
+    const bool spread = split != nullptr && tmp != nullptr && s_trivial != 0u;
+    uint32_t *sorted = spread ? tmp : order;  // [head] [whole, worth something] [whole, trivial] [moved]
+    for (uint32_t g = t; g < n_groups; g += 1024u) {
+        const uint32_t b = bucket(cost[g]);
+        const uint32_t r = atomicAdd(&s_count[b], 1u);  // the group's rank inside its bucket
+        sorted[r < s_take[b] ? tail_at + s_moved_before[b] + r : s_start[b] - s_moved_before[b] + (r - s_take[b])] = g;
+    }
+    if (!spread) return;
+    __threadfence_block();
+    __syncthreads();
+    // position j of the whole part holds a trivial group iff floor((j + 1) * trivial / len) > floor(j * trivial / len)
+    const uint32_t head = s_head, len = tail_at - head, trivial = s_trivial, worth = len - trivial;
+    for (uint32_t k = t; k < n_groups; k += 1024u) {
+        uint32_t src = k;
+        if (k >= head && k < tail_at) {
+            const uint32_t j = k - head;
+            const uint32_t before = uint32_t((uint64_t(j) * trivial) / len), upto = uint32_t((uint64_t(j + 1u) * trivial) / len);
+            src = head + (upto > before ? worth + before : j - before);
+        }
+        order[k] = sorted[src];
+    }
 }
 // order_and_cost: 2 x n_groups dwords; fills the first half with the launch order of P's pixel groups
 // ... from the cost model (measured == null), or from the costs a previous launch of the same layout measured
-extern "C" hipError_t rt_launch_tile_order(const KernelParams *P, uint32_t *order_and_cost, const uint32_t *measured, hipStream_t stream) {
+// split: device address of two dwords (head_groups, whole_end of a mixed launch), or null; slots: wave slots of the device
+// measured_slices: the slices of the launch that measured
+extern "C" hipError_t rt_launch_tile_order(const KernelParams *P, uint32_t *order_and_cost, const uint32_t *measured, uint32_t *split, uint32_t slots,
+                                           uint32_t measured_slices, hipStream_t stream) {
     (void)hipGetLastError();
     const uint32_t tiles_x = (P->width + RT_TILE_W - 1u) / RT_TILE_W, tiles_y = (P->owned_rows + RT_TILE_H - 1u) / RT_TILE_H;
     const uint32_t n = tiles_x * tiles_y;
     if (n == 0) return hipSuccess;
     if (!measured) hipLaunchKernelGGL(tile_cost_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, *P, n, order_and_cost + n);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, measured ? measured : order_and_cost + n, n, order_and_cost);
+    // (the second half of order_and_cost holds the model's costs, or — sorting measurements — serves as scratch)
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, measured ? measured : order_and_cost + n, n, order_and_cost, split,
+                       measured ? order_and_cost + n : (uint32_t *)nullptr, float(slots), 4.0f * float(measured_slices), float(measured_slices));
     return hipGetLastError();
 }
 
@@ -2203,14 +2306,16 @@ static void launch_variant(const KernelParams &P, bool lights, uint32_t blocks, 
     // var — MODE_BVH: RTHIP_F_TILE_LISTS, the instantiation with the primary-visibility list code; MODE_LDS: one-wave workgroups
     // (MODE_BVH always has them: 256 / wgt workgroups per pixel group)
     constexpr bool can_var = MODE == MODE_BVH || (MODE == MODE_LDS && !STATS && RT_SCAN_WAVE_WG);
+    // pixel groups x slices (a mixed launch: its sliced groups x slices + its whole groups)
+    const uint32_t units = P.mixed ? (P.n_groups - (P.whole_end - P.head_groups)) * P.n_slices + (P.whole_end - P.head_groups) : blocks * P.n_slices;
     if (can_var && var) {
         constexpr uint32_t wgt = RT_WG_THREADS(MODE, true);
-        const dim3 grid(blocks * P.n_slices * (256u / wgt)), block(wgt);
+        const dim3 grid(units * (256u / wgt)), block(wgt);
         if (lights) hipLaunchKernelGGL((render_kernel<STATS, MODE, true, SPH_SCENE, can_var>), grid, block, lds, stream, P);
         else hipLaunchKernelGGL((render_kernel<STATS, MODE, false, SPH_SCENE, can_var>), grid, block, lds, stream, P);
     } else {
         constexpr uint32_t wgt = RT_WG_THREADS(MODE, false);
-        const dim3 grid(blocks * P.n_slices * (256u / wgt)), block(wgt);
+        const dim3 grid(units * (256u / wgt)), block(wgt);
         if (lights) hipLaunchKernelGGL((render_kernel<STATS, MODE, true, SPH_SCENE>), grid, block, lds, stream, P);
         else hipLaunchKernelGGL((render_kernel<STATS, MODE, false, SPH_SCENE>), grid, block, lds, stream, P);
     }
@@ -2292,7 +2397,9 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
     else launch_mode<false>(P, mode, lights, blocks, lds, var, stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || P.n_slices == 1) return e;
-    const uint32_t rblocks = uint32_t((uint64_t(P.owned_rows) * P.width + 255u) / 256u);
+    uint32_t rblocks = uint32_t((uint64_t(P.owned_rows) * P.width + 255u) / 256u);
+    if (P.mixed) rblocks = P.n_groups - (P.whole_end - P.head_groups);  // one workgroup per sliced pixel group
+    if (rblocks == 0) return e;
     hipLaunchKernelGGL(resolve_kernel, dim3(rblocks), dim3(256), 0, stream, P);
     return hipGetLastError();
 }

@@ -17,7 +17,8 @@
 #include "rt_device.h"
 #include "rt_prepass.h"
 
-extern "C" hipError_t rt_launch_tile_order(const KernelParams *P, uint32_t *order_and_cost, const uint32_t *measured, hipStream_t stream);
+extern "C" hipError_t rt_launch_tile_order(const KernelParams *P, uint32_t *order_and_cost, const uint32_t *measured, uint32_t *split, uint32_t slots,
+                                           uint32_t measured_slices, hipStream_t stream);
 extern "C" hipError_t rt_launch_prepass(const KernelParams *P, void *tile_pre, hipStream_t stream);
 extern "C" hipError_t rt_launch_render(const KernelParams *P, int count_stats, hipStream_t stream);
 extern "C" hipError_t rt_launch_compact(const KernelParams *P, uint32_t *list, uint32_t *count, hipStream_t stream);
@@ -78,6 +79,9 @@ struct rthip_ctx {
         }
     } order_key = {};
     int order_state = 0;
+    uint32_t order_meas_slices = 1;            // slices of the pass that measured
+    uint32_t order_head = 0, order_whole_end = 0;  // the mixed launch of the measured order (KernelParams::head_groups / whole_end)
+    uint32_t wave_slots = 7168;                // resident waves of the device at 7 per SIMD
     uint64_t frame_gen = 1;                    // advances with every scene upload and camera change
     const void *pre_lists = nullptr;           // the primary-visibility lists (rt_prepass.h) made for the running sum's frame, if any:
                                                // RTHIP_F_ACCUMULATE passes of the same frame reuse them (same camera, scene, layout)
@@ -280,6 +284,10 @@ int rthip_create(int device, rthip_ctx **out_ctx) {
         ctx->pick_out.bytes = sizeof(long long);
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->stats_host, RT_STAT_SHARDS * RT_STAT_N * sizeof(unsigned long long), hipHostMallocDefault));
         // the device address of the static scratch array, once per device, with that device current (each GPU holds its own copy)
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->wave_slots = uint32_t(prop.multiProcessorCount) * 28u;
+        }
         HIPCHK(ctx, rt_scratch_init(device));
         ctx->scratch = rt_scratch_ptr(device);
         if (!ctx->scratch) return fail(ctx, RTHIP_E_INTERNAL, "the scratch array has no device address");
@@ -683,6 +691,7 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         }
         while (uint64_t(k.slice_spp) * max_slices < p->spp) k.slice_spp *= 2;  // a power of two (the kernels mask with slice_spp - 1)
         k.n_slices = (p->spp + k.slice_spp - 1) / k.slice_spp;
+        const uint32_t full_slices = k.n_slices;  // the sample groups of a pixel's sum
         const uint64_t groups = (p->flags & RTHIP_F_ADAPTIVE) && accumulate ? (uint64_t(rows) * p->width + 255u) / 256u
                                                                              : uint64_t((p->width + RT_TILE_W - 1u) / RT_TILE_W) * ((rows + RT_TILE_H - 1u) / RT_TILE_H);
         if (tree_scene ? groups * 4u >= RT_TREE_SLICE_BELOW_WAVES : groups >= RT_SLICE_BELOW_BLOCKS) k.n_slices = 1;
@@ -692,15 +701,26 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         //    layout: row order, sliced) they start longest-first and need NO slices — the heavy tiles start at t = 0 and the launch
         //    ends with sky tiles, without the ramp-down every slice costs: C4 54.4 (4 slices) -> 49.9 ms. Launches that are not
         //    sliced anyway gain nothing from the order (C5: 397.9 vs 397.3 ms) and keep the row order (neighbouring tiles side by side).
-        static const bool order_all = getenv("RTHIP_ORDER_ALL") != nullptr, order_none = getenv("RTHIP_NO_TILE_ORDER") != nullptr,
-                          order_model_only = getenv("RTHIP_ORDER_MODEL_ONLY") != nullptr, order_tree = getenv("RTHIP_NO_TREE_ORDER") == nullptr;
-        const bool scan_ordered = !tree_scene && k.n_spheres <= RT_LDS_SPHERES && p->spp >= RT_ORDER_MIN_SPP && (groups < RT_SLICE_BELOW_BLOCKS || order_all);
+        //  * those scan launches, once measured, are MIXED: of the groups in order of cost, those whose waves would be long against
+        //    the whole launch are traced slice by slice, the bulk in one piece (no ramp-down, no partial sums), and the cheapest that
+        //    are worth it again in slices, so that the launch ends with short pieces (tile_order_kernel computes the two boundaries
+        //    from the measurements). A 1/8-frame launch comes out sliced but for its sky, a 1/2-frame launch 75 % whole: 6.39 -> 6.15 ms.
+        //    The whole 4K frame (RTHIP_MIXED_ALL=1) does NOT gain: a mixed launch keeps 6 900 of its 7 168 wave slots busy until 0.1 ms
+        //    before its end (tools/timeline_mixed.py) and takes 12.2 ms against the 12.05 of the plain row-order launch, whose last
+        //    millisecond runs half empty — the kernel is bound by instruction issue, the waves of a draining GPU run faster, and the
+        //    slices cost their ramp-down. Whole frames keep the row order and are not measured.
+        static const bool order_none = getenv("RTHIP_NO_TILE_ORDER") != nullptr, order_model_only = getenv("RTHIP_ORDER_MODEL_ONLY") != nullptr,
+                          order_tree = getenv("RTHIP_NO_TREE_ORDER") == nullptr, no_mixed = getenv("RTHIP_NO_MIXED") != nullptr,
+                          mixed_all = getenv("RTHIP_MIXED_ALL") != nullptr;
+        const bool scan_ordered = !tree_scene && k.n_spheres <= RT_LDS_SPHERES && p->spp >= RT_ORDER_MIN_SPP && (groups < RT_SLICE_BELOW_BLOCKS || mixed_all);
         const bool tree_ordered = tree_scene && k.n_bvh_nodes > 0 && order_tree && p->spp >= RT_TREE_SLICE_SPP && groups * 4u < RT_TREE_SLICE_BELOW_WAVES;
         const bool ordered = !noalloc && !adaptive && groups >= 64 && (scan_ordered || tree_ordered) && !order_none;
         const rthip_ctx::OrderKey order_key = {p->width, p->height, rows, p->band_rows, p->band_first, p->band_stride, p->spp, p->max_depth,
                                                p->flags & (RTHIP_F_POINT_LIGHTS | RTHIP_F_COUNT_STATS | RTHIP_F_COUNT_EXECUTED), ctx->frame_gen};
         const bool order_measured = ordered && ctx->order_state != 0 && ctx->order_key == order_key && !order_model_only;  // this pass starts its groups by measured cost
         if (tree_ordered && order_measured) k.n_slices = 1;
+        const bool mixed = scan_ordered && order_measured && full_slices > 1 && !no_mixed;
+        if (mixed) k.n_slices = full_slices;  // (the partial sums are addressed as in a sliced launch; only the sliced groups' are touched)
         if (k.n_slices > 1) {
             const size_t need = size_t(k.n_slices) * rows * p->width * 3 * sizeof(float);
             if (noalloc) {
@@ -774,22 +794,41 @@ static int render_pass(rthip_ctx *ctx, const rthip_render_params *p, void *d_rgb
         // progressive loop, not for work-list passes.
         k.tile_order = nullptr;
         k.tile_cost_out = nullptr;
+        k.mixed = 0, k.head_groups = 0, k.whole_end = 0, k.n_groups = uint32_t(groups);
         if (ordered) {
-            if ((st = ensure(ctx, ctx->tile_order, size_t(groups) * 2u * sizeof(uint32_t)))) return st;
+            if ((st = ensure(ctx, ctx->tile_order, (size_t(groups) * 2u + 2u) * sizeof(uint32_t)))) return st;
             if ((st = ensure(ctx, ctx->tile_cost, size_t(groups) * sizeof(uint32_t)))) return st;
+            uint32_t *order = (uint32_t *)ctx->tile_order.p, *split = order + 2u * groups;
             if (order_measured && ctx->order_state == 2) {
                 // the measured order is in place
             } else if (order_measured) {
-                HIPCHK(ctx, rt_launch_tile_order(&k, (uint32_t *)ctx->tile_order.p, (const uint32_t *)ctx->tile_cost.p, stream));
+                HIPCHK(ctx, rt_launch_tile_order(&k, order, (const uint32_t *)ctx->tile_cost.p, mixed ? split : nullptr, ctx->wave_slots, ctx->order_meas_slices, stream));
+                if (mixed) {  // the grid of a mixed launch depends on its two boundaries: read them, once per frame layout
+                    uint32_t hs[2] = {0, 0};
+                    HIPCHK(ctx, hipMemcpyAsync(hs, split, sizeof hs, hipMemcpyDeviceToHost, stream));
+                    HIPCHK(ctx, hipStreamSynchronize(stream));
+                    ctx->order_head = hs[0] <= hs[1] ? hs[0] : hs[1];
+                    ctx->order_whole_end = hs[1] <= groups ? hs[1] : uint32_t(groups);
+                    static const bool dbg = getenv("RTHIP_ORDER_DEBUG") != nullptr;
+                    if (dbg) fprintf(stderr, "[rthip] mixed launch: %u groups = %u sliced + %u whole + %u sliced, %u slices\n", unsigned(groups), ctx->order_head,
+                                     ctx->order_whole_end - ctx->order_head, unsigned(groups) - ctx->order_whole_end, k.n_slices);
+                }
                 ctx->order_state = 2;
             } else {
                 HIPCHK(ctx, hipMemsetAsync(ctx->tile_cost.p, 0, size_t(groups) * sizeof(uint32_t), stream));
-                if (!tree_scene) HIPCHK(ctx, rt_launch_tile_order(&k, (uint32_t *)ctx->tile_order.p, nullptr, stream));
+                // (a cost model for the launches that are sliced from the start; bigger ones and tree scenes start in row order)
+                const bool model = !tree_scene && k.n_slices > 1;
+                if (model) HIPCHK(ctx, rt_launch_tile_order(&k, order, nullptr, nullptr, ctx->wave_slots, 1u, stream));
                 k.tile_cost_out = (uint32_t *)ctx->tile_cost.p;
                 ctx->order_key = order_key;
                 ctx->order_state = 1;
+                ctx->order_meas_slices = k.n_slices;
+                if (model) k.tile_order = order;
             }
-            if (!tree_scene || ctx->order_state == 2) k.tile_order = (const uint32_t *)ctx->tile_order.p;
+            if (ctx->order_state == 2) {
+                k.tile_order = order;
+                if (mixed) k.mixed = 1u, k.head_groups = ctx->order_head, k.whole_end = ctx->order_whole_end;
+            }
         }
         if (make_lists) {
             HIPCHK(ctx, rt_launch_prepass(&k, (void *)k.tile_pre, stream));
