@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools"); sys.path.insert(0, "/root/repo/tests")
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tools")); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, oracle
 from fuzz_parity import random_scene
 from rustracer_amd import Raytracer, abi, flatten, make_params
