@@ -8,7 +8,7 @@ fn main() {
     let hipcc = env::var("HIPCC").unwrap_or_else(|_| "/opt/rocm/bin/hipcc".into());
     let lib = out.join("librthip.so");
     let status = Command::new(&hipcc)
-        .args(&["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-shared", "-o"])
+        .args(&["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-structurizecfg-skip-uniform-regions=1", "-mllvm", "-enable-gvn-hoist", "-shared", "-o"])
         .arg(&lib)
         .arg(csrc.join("rt_kernels.hip"))
         .arg(csrc.join("rthip_api.cpp"))
