@@ -196,6 +196,9 @@ __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
     s.ref = 0;  // the root is always an inner node
     s.sp = 0;
 }
+#ifndef RT_BVH_VISITS_PER_CHECK
+#define RT_BVH_VISITS_PER_CHECK 2 /* node visits per look at how many lanes wait at a leaf (two ballots and a branch per look): 1 -> 2: C4 46.4 -> 45.5 ms; 3: C5 +2 % */
+#endif
 #ifndef RT_BVH_LDS_LEVELS
 #define RT_BVH_LDS_LEVELS 6u
 #endif
@@ -203,7 +206,7 @@ __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
 #define RT_BVH_TOP_NODES 0  /* > 0: stage that many nodes of the top of the tree in LDS — measured slower at every size */
 #endif
 #ifndef RT_BVH_LEAF_LANES
-#define RT_BVH_LEAF_LANES 16
+#define RT_BVH_LEAF_LANES 12 /* (16 until the end of round 3; with two visits per look 12 is 1 % faster on C5, 8 and 20 slower) */
 #endif
 #ifndef RT_BVH_YIELD_LANES
 #define RT_BVH_YIELD_LANES 40
@@ -322,6 +325,7 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
               if (ref < RT_BVH_DONE) cnt[RT_STAT_SHADOW]++;
           }
 #endif
+          auto visit = [&]() {
           if (ref < RT_BVH_DONE) {
             // {frame x, y, z, ref0} {q x, y, z, ref1}. RT_BVH_TOP_NODES > 0: the first n_top nodes (the top of the tree, breadth-first)
             // are staged in LDS
@@ -366,6 +370,14 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
                 ref = RT_BVH_DONE;
             }
           }
+          };
+          visit();
+#if RT_BVH_VISITS_PER_CHECK > 1
+          visit();  // (a second node before the wave looks at how many lanes wait at a leaf)
+#endif
+#if RT_BVH_VISITS_PER_CHECK > 2
+          visit();
+#endif
           if (__popcll(__ballot(ref > RT_BVH_DONE)) >= RT_BVH_LEAF_LANES) break;
         }
         if (ref > RT_BVH_DONE) {  // leaf
