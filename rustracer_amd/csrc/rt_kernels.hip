@@ -200,7 +200,7 @@ __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
 #define RT_BVH_VISITS_PER_CHECK 2 /* node visits per look at how many lanes wait at a leaf (two ballots and a branch per look): 1 -> 2: C4 46.4 -> 45.5 ms; 3: C5 +2 % */
 #endif
 #ifndef RT_BVH_LDS_LEVELS
-#define RT_BVH_LDS_LEVELS 6u
+#define RT_BVH_LDS_LEVELS 7u
 #endif
 #ifndef RT_BVH_TOP_NODES
 #define RT_BVH_TOP_NODES 0  /* > 0: stage that many nodes of the top of the tree in LDS — measured slower at every size */
@@ -694,8 +694,8 @@ __device__ __forceinline__ void finish_pixel(const KernelParams &P, size_t oi, f
 //    idle lanes come from divergent shading branches, not from unequal pixels — hence not used there.)
 //
 // Dynamic LDS layout (bytes): [MODE_LDS: padded n_spheres x 16 geometry | 4 x n_spheres x 16 shading | 64 x 16 camera terms]
-// [MODE_BVH, per wave (a workgroup is one wave there): bvh_levels x 64 x 4 traversal stack | 64 x 4 RNG keys of the tile's pixels + 8 x 4
-// image rows of the tile's rows (work-list passes: 64 x 4 x | y << 16) | 3 x 64*ring_rows x 4 radiance slots | 16 x 4 finished paths
+// [MODE_BVH, per wave (a workgroup is one wave there): bvh_levels x 64 x 4 traversal stack | 8 x 4 image rows of the tile's rows
+// (work-list passes: 64 x 4 x | y << 16) | 3 x 64*ring_rows x 4 radiance slots | 16 x 4 finished paths
 // per ring row | 16 x 8 "ended at a texture" masks per ring row]; rt_launch_render computes the size.
 // MODE_BVH needs resident waves to cover its node fetches (every visit is a dependent, divergent 32-byte fetch): its speed follows
 // the number of waves (measured on C4/C5: 4 -> 5 -> 6 -> 7 waves per SIMD = 1.00 / 1.11 / 1.18 / 1.21), so the kernel is held to
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE, VAR), STATS ? 4 : (LIGHTS ? (MO
     uint32_t *s_stack = (uint32_t *)(s_shade_mem + (MODE == MODE_LDS ? RT_SHADE_RECS * P.n_spheres : 0u));
     // MODE_BVH, per wave: the RNG key of each of its pixels, then the image row of each of its tile's 8 rows (72 dwords) — or, for the
     // scattered pixels of a work-list pass, x | y << 16 of each pixel (128 dwords)
-    const uint32_t pix_dwords = P.worklist ? 128u : 72u;
+    const uint32_t pix_dwords = P.worklist ? 64u : 8u;
     uint32_t *s_pix_all = s_stack + (MODE == MODE_BVH ? P.bvh_levels * WGT : 0u);
     float *s_L_all = (float *)(s_pix_all + (MODE == MODE_BVH ? pix_dwords * WGW : 0u));
     // MODE_BVH: the staged top of the tree sits behind the ring and its row counters (rt_launch_render sizes it)
@@ -939,9 +939,8 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE, VAR), STATS ? 4 : (LIGHTS ? (MO
             pp.z = fmaf(P.vz, pv, fmaf(P.hz, pu, P.d00z));
             pp.w = __uint_as_float(rt_pixel_key(rt_seed_key(P.seed), y * P.width + x));
             if (POOL) {
-                s_pix[lane] = __float_as_uint(pp.w);
-                if (P.worklist) s_pix[64u + lane] = x | (y << 16);
-                else if ((lane & 7u) == 0u) s_pix[64u + (lane >> 3)] = y;
+                if (P.worklist) s_pix[lane] = x | (y << 16);
+                else if ((lane & 7u) == 0u) s_pix[lane >> 3] = y;
             }
             pp_own = pp;
         }
@@ -1282,17 +1281,17 @@ __global__ __launch_bounds__(RT_WG_THREADS(MODE, VAR), STATS ? 4 : (LIGHTS ? (MO
             uint32_t k = key + RT_RNG_GOLDEN;  // RNG slot 1 + bounce
             if (POOL) {
                 if (fresh) {
-                    // the pixel's key (4 B of LDS per pixel) and coordinates (its row's y from the tile's 8-entry table, x from the tile's
-                    // first column); its base direction is recomputed: 10 instructions per path are nothing next to a traversal, and
-                    // LDS is what limits the resident waves (rt_launch_render)
-                    const uint2 px = make_uint2(s_pix[pixel], 0u);
+                    // the pixel's coordinates (its row's y from the tile's 8-entry table, x from the tile's first column; a work-list
+                    // pass keeps x | y << 16 per pixel); its RNG key and base direction are recomputed: 20 instructions per path are
+                    // nothing next to a traversal, and LDS is what limits the resident waves (rt_launch_render)
                     uint32_t fx = x_tile0 + (pixel & 7u), fy;
                     if (P.worklist) {
-                        const uint32_t xy = s_pix[64u + pixel];
+                        const uint32_t xy = s_pix[pixel];
                         fx = xy & 0xffffu, fy = xy >> 16;
                     } else {
-                        fy = s_pix[64u + (pixel >> 3)];
+                        fy = s_pix[pixel >> 3];
                     }
+                    const uint2 px = make_uint2(rt_pixel_key(rt_seed_key(P.seed), fy * P.width + fx), 0u);
                     const float pu = float(fx) * P.inv_wm1, pv = float(fy) * P.inv_hm1;
                     pp.x = fmaf(P.vx, pv, fmaf(P.hx, pu, P.d00x));
                     pp.y = fmaf(P.vy, pv, fmaf(P.hy, pu, P.d00y));
@@ -2381,13 +2380,13 @@ extern "C" hipError_t rt_launch_render(const KernelParams *Pin, int count_stats,
         if (const char *e = getenv("RTHIP_BVH_TOP")) top = RT_BVH_TOP_NODES > 0 ? uint32_t(atoi(e)) : 0u;
         if (top > P.bvh_top_nodes) top = P.bvh_top_nodes;
         P.bvh_top_nodes = top;
-        // per wave: stack levels x 64 lanes, the pixel table (72 dwords; 128 in a work-list pass), 3 colour planes x ring rows x 64 radiance slots,
+        // per wave: stack levels x 64 lanes, the pixel table (8 dwords; 64 in a work-list pass), 3 colour planes x ring rows x 64 radiance slots,
         // 16 row counters, 16 row masks
         const uint32_t waves = RT_WG_THREADS(MODE_BVH, false) / 64u;
-        // (gfx950 hands out LDS in blocks of 1280 B, 128 per CU: 6 levels + the pixel keys + a ring of 4 rows = 5088 B = 4 blocks per one-wave
+        // (gfx950 hands out LDS in blocks of 1280 B, 128 per CU: 7 levels + the row table + a ring of 4 rows = 5088 B = 4 blocks per one-wave
         // workgroup, so 28 waves fit a CU = the 7 per SIMD that 72 VGPRs allow; at 5 blocks (8 levels and a wider pixel table, round 2) 25 fit.
         // Measured with RTHIP_STACK_LDS, tools/stack_lds_sweep.py: C4 56.1 / 56.6 / 57.4 ms at 8 / 7 / 6 levels of 5 blocks, 54.5 at 4 blocks.)
-        lds = waves * (P.bvh_levels * 256u + (P.worklist ? 128u : 72u) * 4u + 3u * 64u * 4u * P.ring_rows + 16u * 4u + 16u * 8u) + top * 32u;
+        lds = waves * (P.bvh_levels * 256u + (P.worklist ? 64u : 8u) * 4u + 3u * 64u * 4u * P.ring_rows + 16u * 4u + 16u * 8u) + top * 32u;
     } else {
         P.ring_rows = 1;  // lane = pixel: no radiance slots
         P.bvh_levels = 0;
