@@ -244,6 +244,9 @@ def main():
                 "frac_note": "frac: flops of the reference's algorithm (every ray tested against every shape, SURVEY 8d) / kernel time / peak; "
                              "frac_executed: the same constants over the shape tests the kernel actually executes (RTHIP_F_COUNT_EXECUTED: "
                              "tests culled per 8x8 tile are not counted)",
+                "issue_note": "the kernel is bound by VALU instruction issue: 89 600 wave instructions per wave at 2.48 cycles each = the launch time "
+                              "(profiles/r03c_summary.md); a loop of independent v_fmac_f32 issues one per 2.5-2.6 cycles on this GPU (tools/ubench/exec_rates.hip), "
+                              "not the 2.0 the 157.3 TFLOP/s peak assumes, and the time does not change between 4 and 7 resident waves per SIMD",
                 "traffic": traffic,
                 "kernel_ms_avg": round(kernel_ms, 4),
                 "kernel_ms_slowest_rank": round(kernel_ms_max, 4),
