@@ -2177,6 +2177,9 @@ __global__ __launch_bounds__(256) void tile_cost_kernel(const KernelParams P, ui
     if (P.n_planes + P.n_tris != 0u) w += 3.0f;  // (not tested: they are few in a scan scene)
     cost[g] = w == 0.0f ? 0u : min(15u, 1u + uint32_t(w * 0.75f));
 }
+#ifndef RT_HEAD_FRACTION
+#define RT_HEAD_FRACTION 0.25f
+#endif
 #ifndef RT_TAIL_FACTOR
 #define RT_TAIL_FACTOR 1.0f
 #endif
@@ -2233,7 +2236,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
         const float t_launch = total * work_mult / slots;
         uint32_t head = 0;
         int head_buckets = 0;
-        for (; head_buckets < 1024 && (float(1023 - head_buckets) + 0.5f) * whole_mult > 0.25f * t_launch; head_buckets++) head += s_cnt[head_buckets];
+        for (; head_buckets < 1024 && (float(1023 - head_buckets) + 0.5f) * whole_mult > RT_HEAD_FRACTION * t_launch; head_buckets++) head += s_cnt[head_buckets];
         float fine = 0.0f;  // the work of the groups moved so far
         uint32_t trivial = 0;
         for (int b = 1023; b >= head_buckets; b--) {
