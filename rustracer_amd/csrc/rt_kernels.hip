@@ -196,6 +196,14 @@ __device__ __forceinline__ void bvh_begin(const Ray &r, BvhState &s) {
     s.ref = 0;  // the root is always an inner node
     s.sp = 0;
 }
+#ifndef RT_BVH_LEAF_DEN
+#define RT_BVH_LEAF_DEN 3 /* the wave turns to its leaves once NUM / DEN of the lanes that are still inside the tree wait at one (0: at RT_BVH_LEAF_LANES
+                             lanes, the rule until the end of round 3). A fixed count is too many when few rays of the wave are left and too few when all
+                             64 are: 12 lanes -> a third: C4 44.8 -> 42.5 ms, C5 350.5 -> 348.4; a half: C5 362; 2/5: 352.9; 2/7, 1/4, 1/5: in between */
+#endif
+#ifndef RT_BVH_LEAF_NUM
+#define RT_BVH_LEAF_NUM 1
+#endif
 #ifndef RT_BVH_VISITS_PER_CHECK
 #define RT_BVH_VISITS_PER_CHECK 2 /* node visits per look at how many lanes wait at a leaf (two ballots and a branch per look): 1 -> 2: C4 46.4 -> 45.5 ms; 3: C5 +2 % */
 #endif
@@ -378,7 +386,11 @@ __device__ __forceinline__ bool bvh_run(const KernelParams &P, const Ray &r, uin
 #if RT_BVH_VISITS_PER_CHECK > 2
           visit();
 #endif
+#if RT_BVH_LEAF_DEN
+          if (uint32_t(__popcll(__ballot(ref > RT_BVH_DONE))) * RT_BVH_LEAF_DEN >= uint32_t(__popcll(__ballot(ref != RT_BVH_DONE))) * RT_BVH_LEAF_NUM) break;
+#else
           if (__popcll(__ballot(ref > RT_BVH_DONE)) >= RT_BVH_LEAF_LANES) break;
+#endif
         }
         if (ref > RT_BVH_DONE) {  // leaf
             found |= leaf_test<STATS, ANY>(P, ref, r, self, h, any, cnt);
